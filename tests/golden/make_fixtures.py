@@ -1,0 +1,361 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE (TJUMMG/OCPG) on CPU.
+
+Run in the build container only:  ``python tests/golden/make_fixtures.py [name ...]``
+The reference is imported through ``ref_import.py`` (stand-ins documented there); only inputs that
+cannot be regenerated from a seed, and the reference's outputs, are written (``*.npz``).  No reference
+source text is stored.  Fixture <-> reference map:
+
+  msda_testpy      models/ops/test.py:21-60 protocol (seed 3, shapes, fp64 + fp32) and its gradient cases
+  msda_cases       ms_deform_attn_core_pytorch (ms_deform_attn_func.py:41-61) on larger seeded cases, incl.
+                   sampling points outside the map (zero padding) -- out + grads (fp64 truth, fp32)
+  msda_module      MSDeformAttn.forward (ms_deform_attn.py:80-118), 2-d and 4-d reference points, padding mask
+  transformer      DeformableTransformer.forward (deformable_transformer.py:134-217), 2 enc + 2 dec layers
+  lfm              LFMResizeAdaptive.forward (modules.py:33-61) without / with incoming gauss_map
+  fusion           VisionLanguageFusionModule.forward (segmentation.py:103-113) with key padding
+  dynmask_mso      OCPG.dynamic_mask_with_coords (ocpg.py:475-529) and MSO.forward (decoder.py:31-46)
+  matcher_crit     HungarianMatcher.forward (matcher.py:74-171) and SetCriterion.forward (criterion.py:213-254)
+  e2e_tiny         OCPG.forward + criterion + backward (ocpg.py:197-447), train mode, with / without padding,
+                   plus the eval-mode tail (ocpg.py:401-433)
+  swin3d           Video-Swin pieces (video_swin_transformer.py) -- see gen_swin3d
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))
+import ref_import  # noqa: E402
+import synth  # noqa: E402
+from cases import MSDA_CASES, TINY, level_start, msda_case_inputs, padded_masks, tiny_text  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def save(name, meta, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    out["__meta__"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.0f} KiB, {len(arrays)} arrays)")
+
+
+# ----------------------------------------------------------------------------------------------
+def gen_msda_testpy():
+    ref_import.install()
+    from models.ops.functions.ms_deform_attn_func import ms_deform_attn_core_pytorch as core
+    N, M, D = 1, 2, 2
+    Lq, L, P = 2, 2, 2
+    shapes, lsi = level_start([(6, 4), (3, 2)])
+    S = int(shapes.prod(1).sum())
+    torch.manual_seed(3)
+    arrays = {"shapes": shapes, "level_start": lsi}
+
+    def draw(ch):
+        value = torch.rand(N, S, M, ch) * 0.01
+        loc = torch.rand(N, Lq, M, L, P, 2)
+        attn = torch.rand(N, Lq, M, L, P) + 1e-5
+        attn /= attn.sum(-1, keepdim=True).sum(-2, keepdim=True)
+        return value, loc, attn
+
+    v, l, a = draw(D)                                    # check_forward_equal_with_pytorch_double
+    arrays.update(d_value=v, d_loc=l, d_attn=a, d_out=core(v.double(), shapes, l.double(), a.double()))
+    v, l, a = draw(D)                                    # check_forward_equal_with_pytorch_float
+    arrays.update(f_value=v, f_loc=l, f_attn=a, f_out=core(v, shapes, l, a))
+    chans = [30, 32, 64, 71, 1025]                       # check_gradient_numerical channel list (2048/3096 in the GPU test only)
+    for ch in chans:
+        v, l, a = draw(ch)
+        vd, ld, ad = (x.double().requires_grad_(True) for x in (v, l, a))
+        out = core(vd, shapes, ld, ad)
+        g = synth.rand(f"testpy_go_{ch}", out.shape).double()
+        gv, gl, ga = torch.autograd.grad((out * g).sum(), (vd, ld, ad))
+        arrays.update({f"g{ch}_value": v, f"g{ch}_loc": l, f"g{ch}_attn": a, f"g{ch}_out": out,
+                       f"g{ch}_gv": gv, f"g{ch}_gl": gl, f"g{ch}_ga": ga})
+    save("msda_testpy", {"N": N, "M": M, "D": D, "Lq": Lq, "L": L, "P": P, "grad_channels": chans,
+                         "grad_out": "synth.rand('testpy_go_<ch>', out.shape).double()"}, **arrays)
+
+
+def gen_msda_cases():
+    ref_import.install()
+    from models.ops.functions.ms_deform_attn_func import ms_deform_attn_core_pytorch as core
+    arrays = {}
+    for c in MSDA_CASES:
+        value, shapes, lsi, loc, attn, go = msda_case_inputs(c)
+        for tag, dt in (("64", torch.float64), ("32", torch.float32)):
+            v, l, a = (x.to(dt).requires_grad_(True) for x in (value, loc, attn))
+            out = core(v, shapes, l, a)
+            gv, gl, ga = torch.autograd.grad((out * go.to(dt)).sum(), (v, l, a))
+            n = c["name"]
+            if tag == "64":
+                arrays.update({f"{n}_out64": out, f"{n}_gv64": gv, f"{n}_gl64": gl, f"{n}_ga64": ga})
+            else:
+                arrays.update({f"{n}_out32": out})
+    save("msda_cases", {"cases": MSDA_CASES}, **arrays)
+
+
+# ----------------------------------------------------------------------------------------------
+def gen_msda_module():
+    ref_import.install()
+    from models.ops.modules import MSDeformAttn
+    d, L, M, P = 64, 4, 8, 4
+    shapes_l = [(8, 12), (4, 6), (2, 3), (1, 2)]
+    shapes, lsi = level_start(shapes_l)
+    S = int(shapes.prod(1).sum())
+    N, Lq = 2, 9
+    mod = MSDeformAttn(d, L, M, P)
+    sd = synth.synth_state_dict(synth.shapes_of(mod), seed=2)
+    mod.load_state_dict(sd)
+    arrays = {}
+    pad = torch.cat([m.flatten(1) for m in padded_masks(N, shapes_l, [1.0, 0.75], [1.0, 0.6])], 1)
+    src = synth.rand("mm_src", (N, S, d)).requires_grad_(True)
+    for tag, refdim, q_len in (("r2", 2, S), ("r4", 4, Lq)):
+        query = synth.rand("mm_q" + tag, (N, q_len, d)).requires_grad_(True)
+        ref = synth.rand("mm_ref" + tag, (N, q_len, L, refdim), uniform=True)
+        if refdim == 4:
+            ref = torch.cat([ref[..., :2], ref[..., 2:] * 0.4 + 0.05], -1)
+        out, loc, attn = mod(query, ref, src, shapes, lsi, pad)
+        go = synth.rand("mm_go" + tag, out.shape)
+        params = list(mod.parameters())
+        grads = torch.autograd.grad((out * go).sum(), [query, src] + params)
+        arrays.update({f"{tag}_out": out, f"{tag}_loc": loc, f"{tag}_attn": attn, f"{tag}_gq": grads[0], f"{tag}_gsrc": grads[1]})
+        for (k, _), g in zip(mod.named_parameters(), grads[2:]):
+            arrays[f"{tag}_gp_{k}"] = g
+    save("msda_module", {"d": d, "L": L, "M": M, "P": P, "shapes": shapes_l, "N": N, "Lq": Lq, "seed": 2,
+                         "pad_frac_h": [1.0, 0.75], "pad_frac_w": [1.0, 0.6], "param_shapes": synth.shapes_of(mod)}, pad=pad, **arrays)
+
+
+def gen_transformer():
+    ref_import.install()
+    from models.deformable_transformer import DeformableTransformer
+    d, ffn, L = 64, 128, 4
+    shapes_l = [(8, 12), (4, 6), (2, 3), (1, 2)]
+    tr = DeformableTransformer(d_model=d, nhead=8, num_encoder_layers=2, num_decoder_layers=2, dim_feedforward=ffn,
+                               dropout=0.0, return_intermediate_dec=True, num_feature_levels=L,
+                               dec_n_points=4, enc_n_points=4)
+    from models.ocpg import MLP, _get_clones
+    bbox = _get_clones(MLP(d, d, 4, 3), 2)
+    tr.decoder.bbox_embed = bbox
+    shp = synth.shapes_of(tr)
+    tr.load_state_dict(synth.synth_state_dict(shp, seed=3))
+    B, T, Q = 1, 2, 3
+    N = B * T
+    masks = padded_masks(N, shapes_l, [1.0, 0.75], [0.8, 1.0])
+    srcs = [synth.rand(f"tr_src{i}", (N, d, h, w)).requires_grad_(True) for i, (h, w) in enumerate(shapes_l)]
+    poss = [synth.rand(f"tr_pos{i}", (N, d, h, w)) for i, (h, w) in enumerate(shapes_l)]
+    tgt = synth.rand("tr_tgt", (B, T, Q, d))
+    qe = synth.rand("tr_qe", (Q, d))
+    hs, memory, init_ref, inter_ref, _, _, inter_samples = tr(srcs, tgt, masks, poss, qe)
+    go = synth.rand("tr_go", hs.shape)
+    gm = [synth.rand(f"tr_gm{i}", m.shape) for i, m in enumerate(memory)]
+    loss = (hs * go).sum() + sum((m * g).sum() for m, g in zip(memory, gm))
+    params = dict(tr.named_parameters())
+    grads = torch.autograd.grad(loss, srcs + list(params.values()), allow_unused=True)
+    arrays = dict(hs=hs, init_ref=init_ref, inter_ref=inter_ref, inter_samples=inter_samples)
+    for i, m in enumerate(memory):
+        arrays[f"memory{i}"] = m
+    for i in range(len(srcs)):
+        arrays[f"gsrc{i}"] = grads[i]
+    gn = {}
+    for (k, _), g in zip(params.items(), grads[len(srcs):]):
+        gn[k] = float(g.norm()) if g is not None else None
+    for i, m in enumerate(masks):
+        arrays[f"mask{i}"] = m
+    save("transformer", {"d": d, "ffn": ffn, "L": L, "shapes": shapes_l, "B": B, "T": T, "Q": Q, "seed": 3,
+                         "enc": 2, "dec": 2, "param_shapes": shp, "grad_norms": gn}, **arrays)
+
+
+def gen_lfm():
+    ref_import.install()
+    from models.modules import LFMResizeAdaptive
+    c = 32
+    mod = LFMResizeAdaptive(c, 7)
+    shp = synth.shapes_of(mod)
+    mod.load_state_dict(synth.synth_state_dict(shp, seed=4))
+    x0 = synth.rand("lfm_x0", (3, c, 12, 20)).requires_grad_(True)
+    y0, g0 = mod(x0)
+    x1 = synth.rand("lfm_x1", (3, c, 6, 10)).requires_grad_(True)
+    y1, g1 = mod(x1, g0)
+    x2 = synth.rand("lfm_x2", (3, c, 3, 5)).requires_grad_(True)      # odd sizes: ifft2(s=(h,w)) path
+    y2, g2 = mod(x2, g1)
+    go = [synth.rand(f"lfm_go{i}", y.shape) for i, y in enumerate((y0, y1, y2))]
+    loss = sum((y * g).sum() for y, g in zip((y0, y1, y2), go))
+    params = dict(mod.named_parameters())
+    grads = torch.autograd.grad(loss, [x0, x1, x2] + list(params.values()))
+    arrays = dict(y0=y0, g0=g0, y1=y1, g1=g1, y2=y2, g2=g2, gx0=grads[0], gx1=grads[1], gx2=grads[2])
+    for (k, _), g in zip(params.items(), grads[3:]):
+        arrays["gp_" + k] = g
+    save("lfm", {"c": c, "sigma": 7, "seed": 4, "param_shapes": shp}, **arrays)
+
+
+def gen_fusion():
+    ref_import.install()
+    from models.segmentation import VisionLanguageFusionModule
+    d = 64
+    mod = VisionLanguageFusionModule(d_model=d, nhead=8)
+    shp = synth.shapes_of(mod)
+    mod.load_state_dict(synth.synth_state_dict(shp, seed=5))
+    t, h, w, b, Lt = 2, 3, 5, 2, 6
+    vis = synth.rand("fu_vis", (t, h, w, b, d)).requires_grad_(True)
+    text = synth.rand("fu_text", (Lt, b, d)).requires_grad_(True)
+    tpos = synth.rand("fu_tpos", (Lt, b, d))
+    pm = torch.zeros(b, Lt, dtype=torch.bool)
+    pm[1, 4:] = True
+    out = mod(visual=vis, text=text, text_key_padding_mask=pm, text_pos=tpos, visual_pos=None)
+    go = synth.rand("fu_go", out.shape)
+    params = dict(mod.named_parameters())
+    grads = torch.autograd.grad((out * go).sum(), [vis, text] + list(params.values()))
+    arrays = dict(out=out, gvis=grads[0], gtext=grads[1], pad=pm)
+    for (k, _), g in zip(params.items(), grads[2:]):
+        arrays["gp_" + k] = g
+    save("fusion", {"d": d, "seed": 5, "t": t, "h": h, "w": w, "b": b, "Lt": Lt, "param_shapes": shp}, **arrays)
+
+
+# ----------------------------------------------------------------------------------------------
+def build_tiny(seed=1, **over):
+    cfg = dict(TINY)
+    cfg.update(over)
+    args = ref_import.reference_args(**cfg)
+    B = 2
+    model, crit, _ = ref_import.build_reference_model(args, tiny_text(B))
+    full = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(synth.synth_state_dict(synth.shapes_of(model), seed=seed))
+    return args, cfg, model, crit, full
+
+
+def gen_dynmask_mso():
+    args, cfg, model, crit, _ = build_tiny()
+    from util.misc import NestedTensor
+    b, t, q, c, h, w = 2, 2, 3, 64, 6, 7
+    feats = synth.rand("dm_feat", (b, t, c, h, w)).requires_grad_(True)
+    n_par = model.num_gen_params
+    params = (synth.rand("dm_par", (b, t * q, n_par)) * 0.2).requires_grad_(True)
+    refp = synth.rand("dm_ref", (b, t * q, 2), uniform=True).requires_grad_(True)
+    targets = [{"size": torch.tensor([h * 8, w * 8])}, {"size": torch.tensor([h * 8 - 5, w * 8 - 3])}]
+    out = model.dynamic_mask_with_coords(feats, params, refp, targets)
+    go = synth.rand("dm_go", out.shape)
+    gf, gp, gr = torch.autograd.grad((out * go).sum(), (feats, params, refp))
+    arrays = dict(dm_out=out, dm_gfeat=gf, dm_gpar=gp, dm_gref=gr)
+    # MSO
+    mso = model.mask_refine
+    n = 3
+    pm = synth.rand("mso_pm", (n, 16, 6, 7)).requires_grad_(True)
+    f4 = synth.rand("mso_f4", (n, 256, 12, 14)).requires_grad_(True)
+    f8 = synth.rand("mso_f8", (n, 512, 6, 7)).requires_grad_(True)
+    o = mso(pm.clone(), [NestedTensor(f4, None), NestedTensor(f8, None)])
+    go = synth.rand("mso_go", o.shape)
+    mp = dict(mso.named_parameters())
+    grads = torch.autograd.grad((o * go).sum(), [pm, f4, f8] + list(mp.values()))
+    arrays.update(mso_out=o, mso_gpm=grads[0], mso_gf4=grads[1], mso_gf8=grads[2])
+    for (k, _), g in zip(mp.items(), grads[3:]):
+        arrays["mso_gp_" + k] = g
+    save("dynmask_mso", {"cfg": cfg, "seed": 1, "b": b, "t": t, "q": q, "c": c, "h": h, "w": w, "n_par": n_par,
+                         "sizes": [[h * 8, w * 8], [h * 8 - 5, w * 8 - 3]],
+                         "mso_param_shapes": synth.shapes_of(mso)}, **arrays)
+
+
+def gen_matcher_crit():
+    args, cfg, model, crit, _ = build_tiny()
+    b, t, q, H, W = 2, 2, 3, 64, 96
+    targets = synth.synthetic_targets(b, t, H, W)
+    targets[1]["valid"] = torch.tensor([1, 0])
+    targets[1]["boxes"] = torch.tensor([[0.3, 0.4, 0.2, 0.3], [0.6, 0.5, 0.3, 0.2]])
+    targets[0]["weights"] = synth.rand("mc_heat", (t, H, W), uniform=True) * targets[0]["masks"]
+    outputs = {
+        "pred_logits": synth.rand("mc_logits", (b, t, q, 1)).requires_grad_(True),
+        "pred_boxes": (synth.rand("mc_boxes", (b, t, q, 4), uniform=True) * 0.5 + 0.2).requires_grad_(True),
+        "pred_masks": synth.rand("mc_masks", (b, t, q, H // 2, W // 2)),
+    }
+    ind = model.matcher(outputs, targets)
+    arrays = {"idx_src": torch.stack([i[0] for i in ind]), "idx_tgt": torch.stack([i[1] for i in ind])}
+    # criterion on a synthetic "selected" output set
+    out = {
+        "pred_logits": outputs["pred_logits"], "pred_boxes": outputs["pred_boxes"],
+        "pred_masks": synth.rand("mc_pm", (b, t, H, W)).requires_grad_(True),
+        "pred_masks_low": synth.rand("mc_pml", (b, t, H // 2, W // 2)).requires_grad_(True),
+        "ls_features": synth.rand("mc_ls", (b, t, 12, H // 2, W // 2)).requires_grad_(True),
+        "frames": synth.rand("mc_fr", (b, t, 3, H // 2, W // 2)),
+        "main_matcher_index": ind, "aux_matcher_index": [],
+    }
+    losses, src_m, tgt_m, weak_m = crit(out, targets)
+    wd = crit.weight_dict
+    total = sum(losses[k] * wd[k] for k in losses if k in wd)
+    leaves = [out["pred_logits"], out["pred_boxes"], out["pred_masks"], out["pred_masks_low"], out["ls_features"]]
+    grads = torch.autograd.grad(total, leaves)
+    for k, v in losses.items():
+        arrays["loss_" + k] = v
+    arrays.update(total=total, g_logits=grads[0], g_boxes=grads[1], g_pm=grads[2], g_pml=grads[3], g_ls=grads[4],
+                  src_m=src_m, tgt_m=tgt_m, weak_m=weak_m)
+    save("matcher_crit", {"cfg": cfg, "b": b, "t": t, "q": q, "H": H, "W": W,
+                          "weight_dict": {k: float(v) for k, v in wd.items()}}, **arrays)
+
+
+def run_e2e(model, crit, B, T, H, W, sizes, train=True):
+    from util.misc import NestedTensor
+    clips = [synth.rand(f"e2e_clip{i}", (T, 3, h, w)) for i, (h, w) in enumerate(sizes)]
+    x = torch.zeros(B, T, 3, H, W)
+    mask = torch.ones(B, T, H, W, dtype=torch.bool)
+    targets = []
+    for i, (h, w) in enumerate(sizes):
+        x[i, :, :, :h, :w] = clips[i]
+        mask[i, :, :h, :w] = False
+        targets.append(synth.synthetic_targets(1, T, h, w)[0])
+    model.train(train)
+    crit.train(train)
+    out = model(NestedTensor(x, mask), ["a"] * B, targets)
+    return out, targets
+
+
+def gen_e2e_tiny():
+    arrays, meta = {}, {}
+    for tag, sizes in (("nopad", [(192, 224), (192, 224)]), ("pad", [(192, 224), (160, 200)])):
+        args, cfg, model, crit, full = build_tiny()
+        B, T, H, W = 2, 2, 192, 224
+        out, targets = run_e2e(model, crit, B, T, H, W, sizes)
+        losses, *_ = crit(out, targets)
+        wd = crit.weight_dict
+        total = sum(losses[k] * wd[k] for k in losses if k in wd)
+        total.backward()
+        for k in ("pred_logits", "pred_boxes", "pred_masks", "pred_masks_low", "ls_features"):
+            arrays[f"{tag}_{k}"] = out[k]
+        arrays[f"{tag}_main_idx"] = torch.stack([i[0] for i in out["main_matcher_index"]])
+        arrays[f"{tag}_aux_idx"] = torch.stack([torch.stack([i[0] for i in a]) for a in out["aux_matcher_index"]])
+        for i, a in enumerate(out["aux_outputs"]):
+            arrays[f"{tag}_aux{i}_pred_masks"] = a["pred_masks"]
+            arrays[f"{tag}_aux{i}_pred_boxes"] = a["pred_boxes"]
+        arrays[f"{tag}_total"] = total
+        meta[f"{tag}_losses"] = {k: float(v) for k, v in losses.items()}
+        gn = {k: (float(p.grad.norm()) if p.grad is not None else None) for k, p in model.named_parameters()}
+        meta[f"{tag}_grad_norms"] = gn
+        meta[f"{tag}_total_grad_norm"] = float(torch.norm(torch.stack([p.grad.norm() for p in model.parameters() if p.grad is not None])))
+        for k in ("query_embed.weight", "transformer.level_embed", "class_embed.1.weight", "controller.layers.2.bias",
+                  "transformer.encoder.layers.0.self_attn.sampling_offsets.bias", "input_proj.3.0.bias",
+                  "backbone.0.body.layer2.0.conv1.weight", "mask_refine.out_conv.weight"):
+            arrays[f"{tag}_grad_{k}"] = dict(model.named_parameters())[k].grad
+        meta[f"{tag}_sizes"] = sizes
+        # eval tail
+        args, cfg, model, crit, full = build_tiny()
+        with torch.no_grad():
+            oute, _ = run_e2e(model, crit, B, T, H, W, sizes, train=False)
+        for k in ("pred_logits", "pred_boxes", "pred_masks", "reference_points"):
+            arrays[f"{tag}_eval_{k}"] = oute[k]
+    meta.update(cfg=cfg, seed=1, B=B, T=T, H=H, W=W, state_shapes=full, float_shapes=synth.shapes_of(model),
+                weight_dict={k: float(v) for k, v in wd.items()})
+    save("e2e_tiny", meta, **arrays)
+
+
+GENS = {"msda_testpy": gen_msda_testpy, "msda_cases": gen_msda_cases, "msda_module": gen_msda_module,
+        "transformer": gen_transformer, "lfm": gen_lfm, "fusion": gen_fusion, "dynmask_mso": gen_dynmask_mso,
+        "matcher_crit": gen_matcher_crit, "e2e_tiny": gen_e2e_tiny}
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(GENS)
+    for n in names:
+        GENS[n]()
