@@ -1,0 +1,69 @@
+/* libocpg_hip.so -- C ABI of the MI355X (gfx950) kernels behind OCPG's per-clip hot path.
+ *
+ * Drop-in boundary #2 of SURVEY.md section 8b.  The reference binds its native op through the pybind11
+ * module `MultiScaleDeformableAttention` (models/ops/src/vision.cpp:13-16) whose two entry points are
+ * declared in models/ops/src/ms_deform_attn.h:20-61 and implemented for CUDA in
+ * models/ops/src/cuda/ms_deform_attn_cuda.cu:20-80 (forward) and :83-152 (backward).  The functions below
+ * are what a ctypes / pybind stub for that path binds instead.
+ *
+ * Conventions (all entry points):
+ *   - plain device pointers + sizes, no torch types; every tensor contiguous, row-major, same device;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); launches are asynchronous,
+ *     nothing in the library synchronises or allocates;
+ *   - return 0 on success, a negative hipError_t on a launch/runtime error, -1000-k for the k-th
+ *     argument being invalid (null pointer / non-positive size);
+ *   - outputs are caller-allocated.  Forward outputs are fully overwritten.  In the backward,
+ *     grad_value is ACCUMULATED into (scatter-add): the caller zeroes it first, exactly as
+ *     ms_deform_attn_cuda.cu:121 does with at::zeros_like; grad_loc / grad_attn are fully overwritten;
+ *   - re-entrant and thread-safe (no global state).
+ *
+ * Tensor contract of MSDeformAttn (ms_deform_attn_cuda.cu:28-48):
+ *   value        [N, S, M, D]          S = sum_l H_l*W_l
+ *   shapes       [L, 2]  int64 (H, W)   device memory  (+ optional host copy, see below)
+ *   level_start  [L]     int64          device memory
+ *   loc          [N, Lq, M, L, P, 2]    (x, y) normalised to [0,1]
+ *   attn         [N, Lq, M, L, P]
+ *   out / grad_out [N, Lq, M*D]
+ * Unlike the reference there is no im2col_step chunking and therefore no `N % im2col_step == 0`
+ * restriction (ms_deform_attn_cuda.cu:50-52); any N works.
+ */
+#ifndef OCPG_HIP_H
+#define OCPG_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* replaces ms_deform_attn_forward (ms_deform_attn.h:20-39 -> ms_deform_attn_cuda.cu:20-80), float32 */
+int ocpg_msda_fwd_f32(const float* value, const int64_t* shapes, const int64_t* level_start,
+                      const float* loc, const float* attn,
+                      int N, int S, int M, int D, int L, int Lq, int P,
+                      float* out, void* stream);
+/* float64 variant (AT_DISPATCH_FLOATING_TYPES, ms_deform_attn_cuda.cu:64); used by the test.py protocol */
+int ocpg_msda_fwd_f64(const double* value, const int64_t* shapes, const int64_t* level_start,
+                      const double* loc, const double* attn,
+                      int N, int S, int M, int D, int L, int Lq, int P,
+                      double* out, void* stream);
+
+/* replaces ms_deform_attn_backward (ms_deform_attn.h:41-61 -> ms_deform_attn_cuda.cu:83-152), float32.
+ * shapes_host: optional HOST copy of `shapes` (may be NULL).  When given and Lq == S (self-attention over
+ * the value's own pixels, the encoder case) the LDS-privatised tile kernel can be selected; results are
+ * identical either way up to fp32 summation order. */
+int ocpg_msda_bwd_f32(const float* value, const int64_t* shapes, const int64_t* level_start,
+                      const float* loc, const float* attn, const float* grad_out,
+                      int N, int S, int M, int D, int L, int Lq, int P,
+                      float* grad_value, float* grad_loc, float* grad_attn,
+                      const int64_t* shapes_host, void* stream);
+int ocpg_msda_bwd_f64(const double* value, const int64_t* shapes, const int64_t* level_start,
+                      const double* loc, const double* attn, const double* grad_out,
+                      int N, int S, int M, int D, int L, int Lq, int P,
+                      double* grad_value, double* grad_loc, double* grad_attn, void* stream);
+
+/* library / build identification: returns e.g. "ocpg_hip gfx950 r1" */
+const char* ocpg_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCPG_HIP_H */

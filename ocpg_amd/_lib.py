@@ -1,0 +1,59 @@
+"""ctypes loader for libocpg_hip.so -- the only way the product reaches its kernels.
+
+There is deliberately NO fallback: if the library is missing or a tensor is not on the GPU the call raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libocpg_hip.so")
+_lib = None
+
+_i64p = ctypes.c_void_p
+_vp = ctypes.c_void_p
+_int = ctypes.c_int
+
+# symbol -> argtypes; must list every entry point declared in include/ocpg_hip.h
+SIGNATURES = {
+    "ocpg_msda_fwd_f32": [_vp, _i64p, _i64p, _vp, _vp] + [_int] * 7 + [_vp, _vp],
+    "ocpg_msda_fwd_f64": [_vp, _i64p, _i64p, _vp, _vp] + [_int] * 7 + [_vp, _vp],
+    "ocpg_msda_bwd_f32": [_vp, _i64p, _i64p, _vp, _vp, _vp] + [_int] * 7 + [_vp, _vp, _vp, _vp, _vp],
+    "ocpg_msda_bwd_f64": [_vp, _i64p, _i64p, _vp, _vp, _vp] + [_int] * 7 + [_vp, _vp, _vp, _vp],
+}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -m ocpg_amd.csrc.build` "
+                "(hipcc --offload-arch=gfx950). The HIP extension is mandatory; there is no CPU/PyTorch fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        L.ocpg_hip_version.restype = ctypes.c_char_p
+        _lib = L
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        if status <= -1000:
+            raise RuntimeError(f"{what}: invalid argument #{-status - 1000}")
+        raise RuntimeError(f"{what}: HIP error {-status}")
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(name, t):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a GPU tensor: Not implemented on the CPU")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} tensor has to be contiguous")

@@ -1,0 +1,450 @@
+// MSDeformAttn forward / backward for MI355X (gfx950, wave64) -- hand-written HIP, no CUDA lineage.
+//
+// What it computes is fixed by the reference (models/ops/src/cuda/ms_deform_im2col_cuda.cuh:237-299 forward,
+// :87-159 + :301-403 backward); how it is mapped onto the machine is not:
+//
+//   * a "row" is one (batch b, query q, head m); its D channels are contiguous (value is [N,S,M,D]).
+//     The fast path gives a row G = D/4 lanes, each lane owning one float4 (16 B) of the head's channels, so
+//     a corner fetch of a head is ONE 16-B-per-lane load covering the head's whole 4*D-byte line, and a
+//     wave64 carries 64/G rows (D=32: one query x 8 heads = the query's full 1-KiB output line).
+//   * the per-sample scalar work (pixel coords, bounds tests, bilinear weights, corner offsets) is done ONCE
+//     per row by the row's lanes in parallel (lane j takes samples j, j+G, ...), parked in LDS, and then
+//     re-read as wave-broadcast ds_read_b128 -- the reference redoes it in every one of the D channel
+//     threads (32x redundant for D=32) together with int64 shape loads.
+//   * backward: grad_loc / grad_attn need a sum over the row's D channels; that is a G-lane DPP-free
+//     shuffle reduction in registers instead of the reference's shared-memory + thread-0 serial loop
+//     (cuh:366-381).  grad_value is a float atomic scatter (one dword per lane per instruction).
+//   * no im2col_step chunk loop on the host: one launch per call.
+//
+// The generic kernels (any D, float or double) keep one wave per row with lanes striding over channels;
+// they exist for the reference's test protocol (models/ops/test.py:85: D in {30,71,1025,2048,3096}, fp64).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ocpg_hip.h"
+
+namespace {
+
+constexpr int kMaxLevels = 16;
+
+// One precomputed sample, 32 bytes = two ds_read_b128.
+struct __attribute__((aligned(16))) SampleRec {
+  int off00;      // element offset (in scalars, relative to value[b, 0, m, 0]) of corner (y0, x0); may be "virtual" (negative) when that corner is outside
+  int rowstride;  // W * M * D
+  int mask;       // bit k set <=> corner k (0:(y0,x0) 1:(y0,x1) 2:(y1,x0) 3:(y1,x1)) is inside the map; 0 => sample skipped
+  float a;        // attention weight
+  float ly, lx;   // fractional parts
+  float H, W;     // level size as float (grad_loc scaling)
+};
+
+template <typename T>
+__device__ __forceinline__ void make_sample(T x_n, T y_n, T a, int H, int W, int lstart, int MD, SampleRec& r) {
+  const T h_im = y_n * (T)H - (T)0.5;
+  const T w_im = x_n * (T)W - (T)0.5;
+  r.a = (float)a;
+  r.H = (float)H;
+  r.W = (float)W;
+  r.rowstride = W * MD;
+  if (h_im > (T)-1 && w_im > (T)-1 && h_im < (T)H && w_im < (T)W) {
+    const int y0 = (int)floor(h_im), x0 = (int)floor(w_im);
+    r.ly = (float)(h_im - (T)y0);
+    r.lx = (float)(w_im - (T)x0);
+    const bool y0ok = y0 >= 0, y1ok = y0 + 1 <= H - 1, x0ok = x0 >= 0, x1ok = x0 + 1 <= W - 1;
+    r.mask = (y0ok && x0ok ? 1 : 0) | (y0ok && x1ok ? 2 : 0) | (y1ok && x0ok ? 4 : 0) | (y1ok && x1ok ? 8 : 0);
+    r.off00 = (lstart + y0 * W + x0) * MD;
+  } else {
+    r.ly = r.lx = 0.f;
+    r.mask = 0;
+    r.off00 = 0;
+  }
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// ------------------------------------------------------------------------------------------------------
+// Fast forward: D = 4*G, G in {1,2,4,8,16,32,64}.  256 threads = 256/G rows per block.
+// LDS: rows_per_block * NS * 32 B (dynamic).
+template <int G>
+__global__ __launch_bounds__(256) void msda_fwd_fast(const float* __restrict__ value, const int64_t* __restrict__ shapes,
+                                                     const int64_t* __restrict__ level_start, const float* __restrict__ loc,
+                                                     const float* __restrict__ attn, int S, int M, int L, int Lq, int P,
+                                                     long long rows, float* __restrict__ out) {
+  constexpr int D = 4 * G;
+  constexpr int ROWS = 256 / G;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  SampleRec* recs = reinterpret_cast<SampleRec*>(smem);
+  __shared__ int lvlH[kMaxLevels], lvlW[kMaxLevels], lvlS[kMaxLevels];
+  const int tid = threadIdx.x;
+  if (tid < L) {
+    lvlH[tid] = (int)shapes[2 * tid];
+    lvlW[tid] = (int)shapes[2 * tid + 1];
+    lvlS[tid] = (int)level_start[tid];
+  }
+  __syncthreads();
+  const int NS = L * P;
+  const int MD = M * D;
+  const int r = tid / G, j = tid % G;
+  const long long row = (long long)blockIdx.x * ROWS + r;
+  const bool live = row < rows;
+  if (live) {
+    const float* lrow = loc + row * NS * 2;
+    const float* arow = attn + row * NS;
+    for (int s = j; s < NS; s += G) {
+      const int l = s / P;
+      SampleRec rec;
+      make_sample<float>(lrow[2 * s], lrow[2 * s + 1], arow[s], lvlH[l], lvlW[l], lvlS[l], MD, rec);
+      recs[r * NS + s] = rec;
+    }
+  }
+  __syncthreads();
+  if (!live) return;
+  const int m = (int)(row % M);
+  const long long b = row / ((long long)Lq * M);
+  const float* vbase = value + b * (long long)S * MD + m * D + 4 * j;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const SampleRec* rr = recs + r * NS;
+#pragma unroll 4
+  for (int s = 0; s < NS; ++s) {
+    const SampleRec rec = rr[s];
+    if (rec.mask == 0) continue;  // uniform across the row's lanes
+    const float hy = 1.f - rec.ly, hx = 1.f - rec.lx;
+    const float* p00 = vbase + rec.off00;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 v1 = (rec.mask & 1) ? ld4(p00) : z;
+    const float4 v2 = (rec.mask & 2) ? ld4(p00 + MD) : z;
+    const float4 v3 = (rec.mask & 4) ? ld4(p00 + rec.rowstride) : z;
+    const float4 v4 = (rec.mask & 8) ? ld4(p00 + rec.rowstride + MD) : z;
+    const float w1 = hy * hx, w2 = hy * rec.lx, w3 = rec.ly * hx, w4 = rec.ly * rec.lx;
+    acc.x += (w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x) * rec.a;
+    acc.y += (w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y) * rec.a;
+    acc.z += (w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z) * rec.a;
+    acc.w += (w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w) * rec.a;
+  }
+  *reinterpret_cast<float4*>(out + row * D + 4 * j) = acc;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Generic forward: one wave per row, lanes stride over channels.  Any D, float or double.
+template <typename T>
+__global__ __launch_bounds__(256) void msda_fwd_generic(const T* __restrict__ value, const int64_t* __restrict__ shapes,
+                                                        const int64_t* __restrict__ level_start, const T* __restrict__ loc,
+                                                        const T* __restrict__ attn, int S, int M, int D, int L, int Lq, int P,
+                                                        long long rows, T* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int NS = L * P;
+  const long long MD = (long long)M * D;
+  const int m = (int)(row % M);
+  const long long b = row / ((long long)Lq * M);
+  const T* vb = value + b * (long long)S * MD + (long long)m * D;
+  for (int c = lane; c < D; c += 64) {
+    T acc = 0;
+    for (int l = 0; l < L; ++l) {
+      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+      const long long ls = level_start[l];
+      for (int p = 0; p < P; ++p) {
+        const long long wi = row * NS + (long long)l * P + p;
+        const T w_im = loc[2 * wi] * (T)W - (T)0.5, h_im = loc[2 * wi + 1] * (T)H - (T)0.5;
+        if (!(h_im > (T)-1 && w_im > (T)-1 && h_im < (T)H && w_im < (T)W)) continue;
+        const int y0 = (int)floor(h_im), x0 = (int)floor(w_im);
+        const T ly = h_im - (T)y0, lx = w_im - (T)x0, hy = (T)1 - ly, hx = (T)1 - lx;
+        const T* p00 = vb + (ls + (long long)y0 * W + x0) * MD + c;
+        const bool y0ok = y0 >= 0, y1ok = y0 + 1 <= H - 1, x0ok = x0 >= 0, x1ok = x0 + 1 <= W - 1;
+        const T v1 = (y0ok && x0ok) ? p00[0] : (T)0;
+        const T v2 = (y0ok && x1ok) ? p00[MD] : (T)0;
+        const T v3 = (y1ok && x0ok) ? p00[(long long)W * MD] : (T)0;
+        const T v4 = (y1ok && x1ok) ? p00[(long long)W * MD + MD] : (T)0;
+        acc += (hy * hx * v1 + hy * lx * v2 + ly * hx * v3 + ly * lx * v4) * attn[wi];
+      }
+    }
+    out[row * D + c] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Fast backward (plain float-atomic scatter for grad_value).
+template <int G>
+__global__ __launch_bounds__(256) void msda_bwd_fast(const float* __restrict__ value, const int64_t* __restrict__ shapes,
+                                                     const int64_t* __restrict__ level_start, const float* __restrict__ loc,
+                                                     const float* __restrict__ attn, const float* __restrict__ gout, int S, int M,
+                                                     int L, int Lq, int P, long long rows, float* __restrict__ gvalue,
+                                                     float* __restrict__ gloc, float* __restrict__ gattn) {
+  constexpr int D = 4 * G;
+  constexpr int ROWS = 256 / G;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  SampleRec* recs = reinterpret_cast<SampleRec*>(smem);
+  __shared__ int lvlH[kMaxLevels], lvlW[kMaxLevels], lvlS[kMaxLevels];
+  const int tid = threadIdx.x;
+  if (tid < L) {
+    lvlH[tid] = (int)shapes[2 * tid];
+    lvlW[tid] = (int)shapes[2 * tid + 1];
+    lvlS[tid] = (int)level_start[tid];
+  }
+  __syncthreads();
+  const int NS = L * P;
+  const int MD = M * D;
+  const int r = tid / G, j = tid % G;
+  const long long row = (long long)blockIdx.x * ROWS + r;
+  const bool live = row < rows;
+  if (live) {
+    const float* lrow = loc + row * NS * 2;
+    const float* arow = attn + row * NS;
+    for (int s = j; s < NS; s += G) {
+      const int l = s / P;
+      SampleRec rec;
+      make_sample<float>(lrow[2 * s], lrow[2 * s + 1], arow[s], lvlH[l], lvlW[l], lvlS[l], MD, rec);
+      recs[r * NS + s] = rec;
+    }
+  }
+  __syncthreads();
+  if (!live) return;  // whole row groups leave together (G divides 64): shuffles below stay within live groups
+  const int m = (int)(row % M);
+  const long long b = row / ((long long)Lq * M);
+  const long long boff = b * (long long)S * MD + m * D + 4 * j;
+  const float* vbase = value + boff;
+  float* gbase = gvalue + boff;
+  const float4 go = ld4(gout + row * D + 4 * j);
+  const SampleRec* rr = recs + r * NS;
+  for (int s = 0; s < NS; ++s) {
+    const SampleRec rec = rr[s];
+    float ga = 0.f, gx = 0.f, gy = 0.f;
+    if (rec.mask != 0) {
+      const float hy = 1.f - rec.ly, hx = 1.f - rec.lx;
+      const float w[4] = {hy * hx, hy * rec.lx, rec.ly * hx, rec.ly * rec.lx};
+      const float dyc[4] = {-hx, -rec.lx, hx, rec.lx};
+      const float dxc[4] = {-hy, hy, -rec.ly, rec.ly};
+      const int offs[4] = {0, MD, rec.rowstride, rec.rowstride + MD};
+      const float4 tg = make_float4(go.x * rec.a, go.y * rec.a, go.z * rec.a, go.w * rec.a);  // top_grad * attn_weight
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 dxs = val, dys = val;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (rec.mask & (1 << k)) {
+          const float4 v = ld4(vbase + rec.off00 + offs[k]);
+          float* g = gbase + rec.off00 + offs[k];
+          atomicAdd(g + 0, w[k] * tg.x);
+          atomicAdd(g + 1, w[k] * tg.y);
+          atomicAdd(g + 2, w[k] * tg.z);
+          atomicAdd(g + 3, w[k] * tg.w);
+          val.x += w[k] * v.x; val.y += w[k] * v.y; val.z += w[k] * v.z; val.w += w[k] * v.w;
+          dxs.x += dxc[k] * v.x; dxs.y += dxc[k] * v.y; dxs.z += dxc[k] * v.z; dxs.w += dxc[k] * v.w;
+          dys.x += dyc[k] * v.x; dys.y += dyc[k] * v.y; dys.z += dyc[k] * v.z; dys.w += dyc[k] * v.w;
+        }
+      }
+      ga = go.x * val.x + go.y * val.y + go.z * val.z + go.w * val.w;
+      gx = rec.W * (dxs.x * tg.x + dxs.y * tg.y + dxs.z * tg.z + dxs.w * tg.w);
+      gy = rec.H * (dys.x * tg.x + dys.y * tg.y + dys.z * tg.z + dys.w * tg.w);
+    }
+    ga = group_sum<G>(ga);
+    gx = group_sum<G>(gx);
+    gy = group_sum<G>(gy);
+    if (j == 0) {
+      gattn[row * NS + s] = ga;
+      *reinterpret_cast<float2*>(gloc + (row * NS + s) * 2) = make_float2(gx, gy);
+    }
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Generic backward: one wave per row; any D; float or double.
+template <typename T>
+__global__ __launch_bounds__(256) void msda_bwd_generic(const T* __restrict__ value, const int64_t* __restrict__ shapes,
+                                                        const int64_t* __restrict__ level_start, const T* __restrict__ loc,
+                                                        const T* __restrict__ attn, const T* __restrict__ gout, int S, int M, int D,
+                                                        int L, int Lq, int P, long long rows, T* __restrict__ gvalue,
+                                                        T* __restrict__ gloc, T* __restrict__ gattn) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;  // wave-uniform
+  const int NS = L * P;
+  const long long MD = (long long)M * D;
+  const int m = (int)(row % M);
+  const long long b = row / ((long long)Lq * M);
+  const long long boff = b * (long long)S * MD + (long long)m * D;
+  for (int l = 0; l < L; ++l) {
+    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+    const long long ls = level_start[l];
+    for (int p = 0; p < P; ++p) {
+      const long long wi = row * NS + (long long)l * P + p;
+      const T w_im = loc[2 * wi] * (T)W - (T)0.5, h_im = loc[2 * wi + 1] * (T)H - (T)0.5;
+      T ga = 0, gx = 0, gy = 0;
+      if (h_im > (T)-1 && w_im > (T)-1 && h_im < (T)H && w_im < (T)W) {
+        const int y0 = (int)floor(h_im), x0 = (int)floor(w_im);
+        const T ly = h_im - (T)y0, lx = w_im - (T)x0, hy = (T)1 - ly, hx = (T)1 - lx;
+        const T a = attn[wi];
+        const bool ok[4] = {y0 >= 0 && x0 >= 0, y0 >= 0 && x0 + 1 <= W - 1, y0 + 1 <= H - 1 && x0 >= 0,
+                            y0 + 1 <= H - 1 && x0 + 1 <= W - 1};
+        const T w[4] = {hy * hx, hy * lx, ly * hx, ly * lx};
+        const T dyc[4] = {-hx, -lx, hx, lx};
+        const T dxc[4] = {-hy, hy, -ly, ly};
+        const long long o00 = boff + (ls + (long long)y0 * W + x0) * MD;
+        const long long offs[4] = {0, MD, (long long)W * MD, (long long)W * MD + MD};
+        for (int c = lane; c < D; c += 64) {
+          const T tg = gout[row * D + c];
+          const T tga = tg * a;
+          T val = 0, dx = 0, dy = 0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (ok[k]) {
+              const T v = value[o00 + offs[k] + c];
+              atomicAdd(gvalue + o00 + offs[k] + c, w[k] * tga);
+              val += w[k] * v;
+              dx += dxc[k] * v;
+              dy += dyc[k] * v;
+            }
+          }
+          ga += tg * val;
+          gx += (T)W * dx * tga;
+          gy += (T)H * dy * tga;
+        }
+      }
+      ga = wave_sum<T>(ga);
+      gx = wave_sum<T>(gx);
+      gy = wave_sum<T>(gy);
+      if (lane == 0) {
+        gattn[wi] = ga;
+        gloc[2 * wi] = gx;
+        gloc[2 * wi + 1] = gy;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+inline int fast_group(int D) {
+  if (D % 4) return 0;
+  const int g = D / 4;
+  if (g < 1 || g > 64 || (g & (g - 1))) return 0;
+  return g;
+}
+
+inline int check_common(const void* a, const void* b, const void* c, const void* d, const void* e, int N, int S, int M, int D,
+                        int L, int Lq, int P) {
+  if (!a) return -1001;
+  if (!b) return -1002;
+  if (!c) return -1003;
+  if (!d) return -1004;
+  if (!e) return -1005;
+  if (N < 0) return -1006;
+  if (S <= 0) return -1007;
+  if (M <= 0) return -1008;
+  if (D <= 0) return -1009;
+  if (L <= 0) return -1010;
+  if (Lq < 0) return -1011;
+  if (P <= 0) return -1012;
+  return 0;
+}
+
+inline int launch_status() {
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+}  // namespace
+
+#define FAST_DISPATCH(G_, KERNEL, ...)                                                          \
+  switch (G_) {                                                                                 \
+    case 1: KERNEL<1><<<grid, 256, lds, st>>>(__VA_ARGS__); break;                               \
+    case 2: KERNEL<2><<<grid, 256, lds, st>>>(__VA_ARGS__); break;                               \
+    case 4: KERNEL<4><<<grid, 256, lds, st>>>(__VA_ARGS__); break;                               \
+    case 8: KERNEL<8><<<grid, 256, lds, st>>>(__VA_ARGS__); break;                               \
+    case 16: KERNEL<16><<<grid, 256, lds, st>>>(__VA_ARGS__); break;                             \
+    case 32: KERNEL<32><<<grid, 256, lds, st>>>(__VA_ARGS__); break;                             \
+    default: KERNEL<64><<<grid, 256, lds, st>>>(__VA_ARGS__); break;                             \
+  }
+
+extern "C" {
+
+const char* ocpg_hip_version(void) { return "ocpg_hip gfx950 r1"; }
+
+int ocpg_msda_fwd_f32(const float* value, const int64_t* shapes, const int64_t* level_start, const float* loc, const float* attn,
+                      int N, int S, int M, int D, int L, int Lq, int P, float* out, void* stream) {
+  if (int e = check_common(value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P)) return e;
+  if (!out) return -1013;
+  const long long rows = (long long)N * Lq * M;
+  if (rows == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int G = fast_group(D);
+  const size_t rec_bytes = (size_t)L * P * sizeof(SampleRec);
+  if (G && L <= kMaxLevels && (256 / G) * rec_bytes <= 48 * 1024 && (long long)S * M * D < (1LL << 31)) {
+    const int rpb = 256 / G;
+    const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
+    const size_t lds = rpb * rec_bytes;
+    FAST_DISPATCH(G, msda_fwd_fast, value, shapes, level_start, loc, attn, S, M, L, Lq, P, rows, out)
+  } else {
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+    msda_fwd_generic<float><<<grid, 256, 0, st>>>(value, shapes, level_start, loc, attn, S, M, D, L, Lq, P, rows, out);
+  }
+  return launch_status();
+}
+
+int ocpg_msda_fwd_f64(const double* value, const int64_t* shapes, const int64_t* level_start, const double* loc,
+                      const double* attn, int N, int S, int M, int D, int L, int Lq, int P, double* out, void* stream) {
+  if (int e = check_common(value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P)) return e;
+  if (!out) return -1013;
+  const long long rows = (long long)N * Lq * M;
+  if (rows == 0) return 0;
+  const unsigned grid = (unsigned)((rows + 3) / 4);
+  msda_fwd_generic<double><<<grid, 256, 0, (hipStream_t)stream>>>(value, shapes, level_start, loc, attn, S, M, D, L, Lq, P, rows, out);
+  return launch_status();
+}
+
+int ocpg_msda_bwd_f32(const float* value, const int64_t* shapes, const int64_t* level_start, const float* loc, const float* attn,
+                      const float* grad_out, int N, int S, int M, int D, int L, int Lq, int P, float* grad_value, float* grad_loc,
+                      float* grad_attn, const int64_t* shapes_host, void* stream) {
+  if (int e = check_common(value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P)) return e;
+  if (!grad_out) return -1013;
+  if (!grad_value) return -1014;
+  if (!grad_loc) return -1015;
+  if (!grad_attn) return -1016;
+  (void)shapes_host;
+  const long long rows = (long long)N * Lq * M;
+  if (rows == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int G = fast_group(D);
+  const size_t rec_bytes = (size_t)L * P * sizeof(SampleRec);
+  if (G && L <= kMaxLevels && (256 / G) * rec_bytes <= 48 * 1024 && (long long)S * M * D < (1LL << 31)) {
+    const int rpb = 256 / G;
+    const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
+    const size_t lds = rpb * rec_bytes;
+    FAST_DISPATCH(G, msda_bwd_fast, value, shapes, level_start, loc, attn, grad_out, S, M, L, Lq, P, rows, grad_value, grad_loc,
+                  grad_attn)
+  } else {
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+    msda_bwd_generic<float><<<grid, 256, 0, st>>>(value, shapes, level_start, loc, attn, grad_out, S, M, D, L, Lq, P, rows,
+                                                  grad_value, grad_loc, grad_attn);
+  }
+  return launch_status();
+}
+
+int ocpg_msda_bwd_f64(const double* value, const int64_t* shapes, const int64_t* level_start, const double* loc,
+                      const double* attn, const double* grad_out, int N, int S, int M, int D, int L, int Lq, int P,
+                      double* grad_value, double* grad_loc, double* grad_attn, void* stream) {
+  if (int e = check_common(value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P)) return e;
+  if (!grad_out) return -1013;
+  if (!grad_value) return -1014;
+  if (!grad_loc) return -1015;
+  if (!grad_attn) return -1016;
+  const long long rows = (long long)N * Lq * M;
+  if (rows == 0) return 0;
+  const unsigned grid = (unsigned)((rows + 3) / 4);
+  msda_bwd_generic<double><<<grid, 256, 0, (hipStream_t)stream>>>(value, shapes, level_start, loc, attn, grad_out, S, M, D, L,
+                                                                   Lq, P, rows, grad_value, grad_loc, grad_attn);
+  return launch_status();
+}
+
+}  // extern "C"

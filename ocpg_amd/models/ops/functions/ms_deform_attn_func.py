@@ -1,0 +1,93 @@
+"""MSDeformAttnFunction -- autograd binding of the HIP op; mirrors the reference's
+models/ops/functions/ms_deform_attn_func.py:21-39 (same ``apply`` signature, same saved tensors, same
+returned gradient tuple) but calls libocpg_hip.so through its C ABI instead of the pybind CUDA module.
+
+Error behaviour follows ms_deform_attn_cuda.cu:28-38 / ms_deform_attn.h:38,60: non-contiguous or CPU tensors
+raise RuntimeError.  ``im2col_step`` is accepted and ignored (no chunking, hence no ``N % step`` restriction).
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from ...._lib import check, lib, require_gpu, stream_ptr
+
+
+def _host_shapes(spatial_shapes):
+    """Host copy of the [L,2] shapes tensor. Our own transformer attaches it (no sync); foreign callers pay one
+    D2H copy -- the reference's module syncs on the same tensor anyway (ms_deform_attn.py:94 assert)."""
+    hs = getattr(spatial_shapes, "_ocpg_host", None)
+    if hs is None:
+        hs = spatial_shapes.detach().cpu().contiguous()
+    return hs
+
+
+def _dims(value, loc):
+    N, S, M, D = value.shape
+    _, Lq, _, L, P, _ = loc.shape
+    return N, S, M, D, L, Lq, P
+
+
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step=64):
+    for n, t in (("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+                 ("sampling_loc", sampling_loc), ("attn_weight", attn_weight)):
+        require_gpu(n, t)
+    if value.dtype not in (torch.float32, torch.float64):
+        raise RuntimeError("ms_deform_attn_forward: only float32 / float64 are supported")
+    if sampling_loc.dtype != value.dtype or attn_weight.dtype != value.dtype:
+        raise RuntimeError("ms_deform_attn_forward: value / sampling_loc / attn_weight dtypes differ")
+    if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64:
+        raise RuntimeError("ms_deform_attn_forward: spatial_shapes / level_start_index must be int64")
+    N, S, M, D, L, Lq, P = _dims(value, sampling_loc)
+    out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+    fn = lib().ocpg_msda_fwd_f32 if value.dtype == torch.float32 else lib().ocpg_msda_fwd_f64
+    with torch.cuda.device(value.device):
+        check(fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
+                 attn_weight.data_ptr(), N, S, M, D, L, Lq, P, out.data_ptr(), stream_ptr()), "ocpg_msda_fwd")
+    return out
+
+
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, im2col_step=64):
+    for n, t in (("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+                 ("sampling_loc", sampling_loc), ("attn_weight", attn_weight), ("grad_output", grad_output)):
+        require_gpu(n, t)
+    N, S, M, D, L, Lq, P = _dims(value, sampling_loc)
+    grad_value = torch.zeros_like(value)
+    grad_loc = torch.empty_like(sampling_loc)
+    grad_attn = torch.empty_like(attn_weight)
+    with torch.cuda.device(value.device):
+        if value.dtype == torch.float32:
+            hs = _host_shapes(spatial_shapes)
+            check(lib().ocpg_msda_bwd_f32(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                                          sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
+                                          N, S, M, D, L, Lq, P, grad_value.data_ptr(), grad_loc.data_ptr(),
+                                          grad_attn.data_ptr(), ctypes.c_void_p(hs.data_ptr()), stream_ptr()), "ocpg_msda_bwd")
+        elif value.dtype == torch.float64:
+            check(lib().ocpg_msda_bwd_f64(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                                          sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
+                                          N, S, M, D, L, Lq, P, grad_value.data_ptr(), grad_loc.data_ptr(),
+                                          grad_attn.data_ptr(), stream_ptr()), "ocpg_msda_bwd")
+        else:
+            raise RuntimeError("ms_deform_attn_backward: only float32 / float64 are supported")
+    return grad_value, grad_loc, grad_attn
+
+
+class MSDeformAttnFunction(Function):
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights, im2col_step):
+        ctx.im2col_step = im2col_step
+        output = ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                                        attention_weights, im2col_step)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights)
+        ctx.shapes_host = getattr(value_spatial_shapes, "_ocpg_host", None)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, level_start, loc, attn = ctx.saved_tensors
+        if ctx.shapes_host is not None:
+            shapes._ocpg_host = ctx.shapes_host
+        gv, gl, ga = ms_deform_attn_backward(value, shapes, level_start, loc, attn, grad_output.contiguous(), ctx.im2col_step)
+        return gv, None, None, gl, ga, None
