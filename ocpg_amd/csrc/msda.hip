@@ -334,11 +334,6 @@ inline int fast_group(int D) {
 
 inline int check_common(const void* a, const void* b, const void* c, const void* d, const void* e, int N, int S, int M, int D,
                         int L, int Lq, int P) {
-  if (!a) return -1001;
-  if (!b) return -1002;
-  if (!c) return -1003;
-  if (!d) return -1004;
-  if (!e) return -1005;
   if (N < 0) return -1006;
   if (S <= 0) return -1007;
   if (M <= 0) return -1008;
@@ -346,6 +341,12 @@ inline int check_common(const void* a, const void* b, const void* c, const void*
   if (L <= 0) return -1010;
   if (Lq < 0) return -1011;
   if (P <= 0) return -1012;
+  if ((long long)N * Lq == 0) return 0;  // empty problem: pointers may legitimately be null
+  if (!a) return -1001;
+  if (!b) return -1002;
+  if (!c) return -1003;
+  if (!d) return -1004;
+  if (!e) return -1005;
   return 0;
 }
 
@@ -374,9 +375,9 @@ const char* ocpg_hip_version(void) { return "ocpg_hip gfx950 r1"; }
 int ocpg_msda_fwd_f32(const float* value, const int64_t* shapes, const int64_t* level_start, const float* loc, const float* attn,
                       int N, int S, int M, int D, int L, int Lq, int P, float* out, void* stream) {
   if (int e = check_common(value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P)) return e;
-  if (!out) return -1013;
   const long long rows = (long long)N * Lq * M;
   if (rows == 0) return 0;
+  if (!out) return -1013;
   hipStream_t st = (hipStream_t)stream;
   const int G = fast_group(D);
   const size_t rec_bytes = (size_t)L * P * sizeof(SampleRec);
@@ -395,9 +396,9 @@ int ocpg_msda_fwd_f32(const float* value, const int64_t* shapes, const int64_t* 
 int ocpg_msda_fwd_f64(const double* value, const int64_t* shapes, const int64_t* level_start, const double* loc,
                       const double* attn, int N, int S, int M, int D, int L, int Lq, int P, double* out, void* stream) {
   if (int e = check_common(value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P)) return e;
-  if (!out) return -1013;
   const long long rows = (long long)N * Lq * M;
   if (rows == 0) return 0;
+  if (!out) return -1013;
   const unsigned grid = (unsigned)((rows + 3) / 4);
   msda_fwd_generic<double><<<grid, 256, 0, (hipStream_t)stream>>>(value, shapes, level_start, loc, attn, S, M, D, L, Lq, P, rows, out);
   return launch_status();
@@ -407,13 +408,13 @@ int ocpg_msda_bwd_f32(const float* value, const int64_t* shapes, const int64_t* 
                       const float* grad_out, int N, int S, int M, int D, int L, int Lq, int P, float* grad_value, float* grad_loc,
                       float* grad_attn, const int64_t* shapes_host, void* stream) {
   if (int e = check_common(value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P)) return e;
+  (void)shapes_host;
+  const long long rows = (long long)N * Lq * M;
+  if (rows == 0) return 0;
   if (!grad_out) return -1013;
   if (!grad_value) return -1014;
   if (!grad_loc) return -1015;
   if (!grad_attn) return -1016;
-  (void)shapes_host;
-  const long long rows = (long long)N * Lq * M;
-  if (rows == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const int G = fast_group(D);
   const size_t rec_bytes = (size_t)L * P * sizeof(SampleRec);
@@ -435,12 +436,12 @@ int ocpg_msda_bwd_f64(const double* value, const int64_t* shapes, const int64_t*
                       const double* attn, const double* grad_out, int N, int S, int M, int D, int L, int Lq, int P,
                       double* grad_value, double* grad_loc, double* grad_attn, void* stream) {
   if (int e = check_common(value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P)) return e;
+  const long long rows = (long long)N * Lq * M;
+  if (rows == 0) return 0;
   if (!grad_out) return -1013;
   if (!grad_value) return -1014;
   if (!grad_loc) return -1015;
   if (!grad_attn) return -1016;
-  const long long rows = (long long)N * Lq * M;
-  if (rows == 0) return 0;
   const unsigned grid = (unsigned)((rows + 3) / 4);
   msda_bwd_generic<double><<<grid, 256, 0, (hipStream_t)stream>>>(value, shapes, level_start, loc, attn, grad_out, S, M, D, L,
                                                                    Lq, P, rows, grad_value, grad_loc, grad_attn);

@@ -1,0 +1,151 @@
+"""ResNet-50/101 spatio-temporal backbone (frames folded into the batch) with frozen BatchNorm.
+
+Mirrors the reference's models/backbone.py (FrozenBatchNorm2d :20-56, BackboneBase :59-85, Backbone :88-100,
+Joiner :103-121, build_backbone :124-131).  The reference takes the conv stack from torchvision
+(backbone.py:94-96); torchvision is not a dependency here -- the body is restated with torchvision's state_dict
+names (conv1, bn1, layerK.i.{conv1,bn1,conv2,bn2,conv3,bn3,downsample.{0,1}}) so reference checkpoints load.
+MI355X notes: frozen BN is applied as one fused multiply-add with a per-channel scale/shift that is computed
+once per forward (the reference runs 4 elementwise kernels per BN); ReLU is fused in place.
+"""
+from typing import List
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..util.misc import NestedTensor
+from .position_encoding import build_position_encoding
+
+_STAGES = {"resnet50": (3, 4, 6, 3), "resnet101": (3, 4, 23, 3)}
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """BatchNorm2d with fixed statistics and affine parameters (all four are buffers, eps = 1e-5)."""
+
+    def __init__(self, n):
+        super().__init__()
+        self.register_buffer("weight", torch.ones(n))
+        self.register_buffer("bias", torch.zeros(n))
+        self.register_buffer("running_mean", torch.zeros(n))
+        self.register_buffer("running_var", torch.ones(n))
+
+    def _load_from_state_dict(self, state_dict, prefix, *a, **k):
+        state_dict.pop(prefix + "num_batches_tracked", None)
+        super()._load_from_state_dict(state_dict, prefix, *a, **k)
+
+    def scale_shift(self):
+        scale = self.weight * (self.running_var + 1e-5).rsqrt()
+        return scale, self.bias - self.running_mean * scale
+
+    def forward(self, x):
+        scale, shift = self.scale_shift()
+        return torch.addcmul(shift.view(1, -1, 1, 1).to(x.dtype), x, scale.view(1, -1, 1, 1).to(x.dtype))
+
+
+class Bottleneck(nn.Module):
+    def __init__(self, cin, width, stride, dilation, project):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, width, 1, bias=False)
+        self.bn1 = FrozenBatchNorm2d(width)
+        self.conv2 = nn.Conv2d(width, width, 3, stride=stride, padding=dilation, dilation=dilation, bias=False)
+        self.bn2 = FrozenBatchNorm2d(width)
+        self.conv3 = nn.Conv2d(width, width * 4, 1, bias=False)
+        self.bn3 = FrozenBatchNorm2d(width * 4)
+        self.downsample = None
+        if project:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, width * 4, 1, stride=stride, bias=False),
+                                            FrozenBatchNorm2d(width * 4))
+
+    def forward(self, x):
+        y = F.relu_(self.bn1(self.conv1(x)))
+        y = F.relu_(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        skip = x if self.downsample is None else self.downsample(x)
+        return F.relu_(y + skip)
+
+
+class ResNetBody(nn.Module):
+    """conv1/bn1/maxpool + layer1..4; returns the requested stage outputs keyed "0".."3"."""
+
+    def __init__(self, name, dilation=False, return_interm_layers=True):
+        super().__init__()
+        depths = _STAGES[name]
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = FrozenBatchNorm2d(64)
+        cin, dil = 64, 1
+        for i, (width, n) in enumerate(zip((64, 128, 256, 512), depths)):
+            stride = 1 if i == 0 else 2
+            first_dil = dil
+            if i == 3 and dilation:
+                dil, stride = dil * 2, 1
+            blocks = [Bottleneck(cin, width, stride, first_dil, project=(stride != 1 or cin != width * 4))]
+            cin = width * 4
+            blocks += [Bottleneck(cin, width, 1, dil, project=False) for _ in range(n - 1)]
+            setattr(self, f"layer{i + 1}", nn.Sequential(*blocks))
+        self.return_layers = {"layer1": "0", "layer2": "1", "layer3": "2", "layer4": "3"} if return_interm_layers else {"layer4": "0"}
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def forward(self, x):
+        x = F.relu_(self.bn1(self.conv1(x)))
+        x = F.max_pool2d(x, 3, stride=2, padding=1)
+        out = {}
+        for name in ("layer1", "layer2", "layer3", "layer4"):
+            x = getattr(self, name)(x)
+            if name in self.return_layers:
+                out[self.return_layers[name]] = x
+        return out
+
+
+class Backbone(nn.Module):
+    """ResNet body; stem + layer1 frozen (backbone.py:63-65), everything frozen when lr_backbone == 0."""
+
+    def __init__(self, name: str, train_backbone: bool, return_interm_layers: bool, dilation: bool):
+        super().__init__()
+        assert name in _STAGES, f"unsupported backbone {name} (number of channels are hard coded)"
+        self.body = ResNetBody(name, dilation, return_interm_layers)
+        for pname, p in self.body.named_parameters():
+            if not train_backbone or not any(k in pname for k in ("layer2", "layer3", "layer4")):
+                p.requires_grad_(False)
+        if return_interm_layers:
+            self.strides, self.num_channels = [4, 8, 16, 32], [256, 512, 1024, 2048]
+        else:
+            self.strides, self.num_channels = [32], [2048]
+        if dilation:
+            self.strides[-1] //= 2
+
+    def forward(self, tensor_list: NestedTensor):
+        m = tensor_list.mask
+        assert m is not None
+        out = {}
+        for name, x in self.body(tensor_list.tensors).items():
+            mask = F.interpolate(m[None].float(), size=x.shape[-2:]).to(torch.bool)[0]
+            out[name] = NestedTensor(x, mask)
+        return out
+
+
+class Joiner(nn.Sequential):
+    def __init__(self, backbone, position_embedding):
+        super().__init__(backbone, position_embedding)
+        self.strides = backbone.strides
+        self.num_channels = backbone.num_channels
+
+    def forward(self, tensor_list: NestedTensor):
+        # NB (reference quirk, backbone.py:111-112): the caller's NestedTensor is folded IN PLACE to [(b t), ...]
+        tensor_list.tensors = tensor_list.tensors.flatten(0, 1)
+        tensor_list.mask = tensor_list.mask.flatten(0, 1)
+        feats: List[NestedTensor] = []
+        pos = []
+        for _, x in self[0](tensor_list).items():
+            feats.append(x)
+            pos.append(self[1](x).to(x.tensors.dtype))
+        return feats, pos
+
+
+def build_backbone(args):
+    position_embedding = build_position_encoding(args)
+    backbone = Backbone(args.backbone, args.lr_backbone > 0, bool(args.masks), args.dilation)
+    model = Joiner(backbone, position_embedding)
+    model.num_channels = backbone.num_channels
+    return model

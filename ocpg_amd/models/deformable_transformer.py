@@ -1,0 +1,236 @@
+"""Multi-scale deformable cross-modal transformer (4 encoder + 4 decoder layers by default).
+
+Behaviour follows the reference's models/deformable_transformer.py: DeformableTransformer.forward :134-217,
+encoder layer :220-259, get_reference_points :268-281, decoder layer :292-336 (self-attn -> cross-attn -> FFN with
+norms named norm2 / norm1 / norm3), decoder :340-398 (top-30 sample export :368-375, iterative box refinement
+:378-388).  Parameter names are identical so reference state_dicts load.
+
+Host-side differences (MI355X-first): level geometry (shapes, level starts) is kept as Python ints next to the
+device tensors (`_ocpg_host`), so no kernel launch depends on a device->host read; the reference point grid and
+the per-level slices are built from those ints.
+"""
+import copy
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..util.misc import inverse_sigmoid
+from .attention import MultiheadAttention
+from .ops.modules import MSDeformAttn
+
+
+def _clones(module, n):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(n)])
+
+
+def _activation(name):
+    if name == "relu":
+        return F.relu
+    if name == "gelu":
+        return F.gelu
+    if name == "glu":
+        return F.glu
+    raise RuntimeError(f"activation should be relu/gelu, not {name}.")
+
+
+class DeformableTransformerEncoderLayer(nn.Module):
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        self.self_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.activation = _activation(activation)
+        self.dropout2 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout3 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+
+    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
+        with torch.autocast(device_type=src.device.type, enabled=False):
+            q = src.float() if pos is None else src.float() + pos.float()
+            attn = self.self_attn(q, reference_points, src.float(), spatial_shapes, level_start_index, padding_mask)[0]
+        src = self.norm1(src + self.dropout1(attn))
+        ffn = self.linear2(self.dropout2(self.activation(self.linear1(src))))
+        return self.norm2(src + self.dropout3(ffn))
+
+
+class DeformableTransformerEncoder(nn.Module):
+    def __init__(self, encoder_layer, num_layers):
+        super().__init__()
+        self.layers = _clones(encoder_layer, num_layers)
+        self.num_layers = num_layers
+
+    @staticmethod
+    def get_reference_points(spatial_shapes, valid_ratios, device):
+        """Pixel-centre grid of every level, normalised by the valid extent, re-scaled per target level: [N, S, L, 2]."""
+        host = getattr(spatial_shapes, "_ocpg_host", None)
+        shapes = host.tolist() if host is not None else spatial_shapes.tolist()
+        per_level = []
+        for lvl, (h, w) in enumerate(shapes):
+            ys = torch.linspace(0.5, h - 0.5, h, dtype=torch.float32, device=device)
+            xs = torch.linspace(0.5, w - 0.5, w, dtype=torch.float32, device=device)
+            gy, gx = torch.meshgrid(ys, xs, indexing="ij")
+            gy = gy.reshape(-1)[None] / (valid_ratios[:, None, lvl, 1] * h)
+            gx = gx.reshape(-1)[None] / (valid_ratios[:, None, lvl, 0] * w)
+            per_level.append(torch.stack((gx, gy), -1))
+        ref = torch.cat(per_level, 1)
+        return ref[:, :, None] * valid_ratios[:, None]
+
+    def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None):
+        ref = self.get_reference_points(spatial_shapes, valid_ratios, src.device)
+        out = src
+        for layer in self.layers:
+            out = layer(out, pos, ref, spatial_shapes, level_start_index, padding_mask)
+        return out
+
+
+class DeformableTransformerDecoderLayer(nn.Module):
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        self.cross_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.self_attn = MultiheadAttention(d_model, n_heads, dropout=dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.activation = _activation(activation)
+        self.dropout3 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout4 = nn.Dropout(dropout)
+        self.norm3 = nn.LayerNorm(d_model)
+
+    def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index, src_padding_mask=None):
+        qk = tgt if query_pos is None else tgt + query_pos
+        sa = self.self_attn(qk.transpose(0, 1), qk.transpose(0, 1), tgt.transpose(0, 1)).transpose(0, 1)
+        tgt = self.norm2(tgt + self.dropout2(sa))
+        with torch.autocast(device_type=tgt.device.type, enabled=False):
+            q = tgt.float() if query_pos is None else tgt.float() + query_pos.float()
+            ca, loc, weights = self.cross_attn(q, reference_points, src.float(), src_spatial_shapes, level_start_index, src_padding_mask)
+        tgt = self.norm1(tgt + self.dropout1(ca))
+        ffn = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
+        return self.norm3(tgt + self.dropout4(ffn)), loc, weights
+
+
+class DeformableTransformerDecoder(nn.Module):
+    TOPK_SAMPLES = 30   # deformable_transformer.py:372-373
+
+    def __init__(self, decoder_layer, num_layers, return_intermediate=False):
+        super().__init__()
+        self.layers = _clones(decoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.return_intermediate = return_intermediate
+        self.bbox_embed = None      # set by OCPG for iterative box refinement
+        self.class_embed = None
+
+    def forward(self, tgt, reference_points, src, src_spatial_shapes, src_level_start_index, src_valid_ratios,
+                query_pos=None, src_padding_mask=None):
+        out = tgt
+        inter, inter_refs, inter_samples = [], [], []
+        samples_keep = None
+        for lid, layer in enumerate(self.layers):
+            if reference_points.shape[-1] == 4:
+                ref_in = reference_points[:, :, None] * torch.cat([src_valid_ratios, src_valid_ratios], -1)[:, None]
+            else:
+                assert reference_points.shape[-1] == 2
+                ref_in = reference_points[:, :, None] * src_valid_ratios[:, None]
+            out, loc, weights = layer(out, query_pos, ref_in, src, src_spatial_shapes, src_level_start_index, src_padding_mask)
+
+            n, lq = loc.shape[:2]
+            loc = loc / src_valid_ratios[:, None, None, :, None, :]
+            top_idx = weights.reshape(n, lq, -1).topk(self.TOPK_SAMPLES, dim=2)[1]
+            samples_keep = torch.gather(loc.reshape(n, lq, -1, 2), 2, top_idx.unsqueeze(-1).expand(-1, -1, -1, 2))
+
+            if self.bbox_embed is not None:
+                delta = self.bbox_embed[lid](out)
+                if reference_points.shape[-1] == 4:
+                    new_ref = (delta + inverse_sigmoid(reference_points)).sigmoid()
+                else:
+                    new_ref = torch.cat([delta[..., :2] + inverse_sigmoid(reference_points), delta[..., 2:]], -1).sigmoid()
+                reference_points = new_ref.detach()
+            if self.return_intermediate:
+                inter.append(out)
+                inter_refs.append(reference_points)
+                inter_samples.append(samples_keep)
+        if self.return_intermediate:
+            return torch.stack(inter), torch.stack(inter_refs), torch.stack(inter_samples)
+        return out, reference_points, samples_keep
+
+
+class DeformableTransformer(nn.Module):
+    def __init__(self, d_model=256, nhead=8, num_encoder_layers=6, num_decoder_layers=6, dim_feedforward=1024,
+                 dropout=0.1, activation="relu", return_intermediate_dec=False, num_feature_levels=4,
+                 dec_n_points=4, enc_n_points=4, two_stage=False, two_stage_num_proposals=300):
+        super().__init__()
+        assert not two_stage, "args.two_stage must be false!"   # ocpg.py:65
+        self.d_model, self.nhead, self.dropout = d_model, nhead, dropout
+        self.two_stage = False
+        self.num_feature_level = num_feature_levels
+        self.encoder = DeformableTransformerEncoder(
+            DeformableTransformerEncoderLayer(d_model, dim_feedforward, dropout, activation, num_feature_levels, nhead, enc_n_points),
+            num_encoder_layers)
+        self.decoder = DeformableTransformerDecoder(
+            DeformableTransformerDecoderLayer(d_model, dim_feedforward, dropout, activation, num_feature_levels, nhead, dec_n_points),
+            num_decoder_layers, return_intermediate_dec)
+        self.level_embed = nn.Parameter(torch.empty(num_feature_levels, d_model))
+        self.reference_points = nn.Linear(d_model, 2)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, MSDeformAttn):
+                m._reset_parameters()
+        nn.init.xavier_uniform_(self.reference_points.weight, gain=1.0)
+        nn.init.zeros_(self.reference_points.bias)
+        nn.init.normal_(self.level_embed)
+
+    @staticmethod
+    def get_valid_ratio(mask):
+        _, h, w = mask.shape
+        vh = (~mask[:, :, 0]).sum(1).float() / h
+        vw = (~mask[:, 0, :]).sum(1).float() / w
+        return torch.stack([vw, vh], -1)
+
+    def forward(self, srcs, tgt, masks, pos_embeds, query_embed=None):
+        """srcs/pos_embeds: L x [(b t), C, h, w]; masks: L x [(b t), h, w]; tgt [b, t, q, C]; query_embed [q, C]."""
+        assert query_embed is not None
+        dev = srcs[0].device
+        shapes_host = [tuple(s.shape[-2:]) for s in srcs]
+        src = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
+        mask = torch.cat([m.flatten(1) for m in masks], 1)
+        pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[l].view(1, 1, -1) for l, p in enumerate(pos_embeds)], 1)
+        host = torch.tensor(shapes_host, dtype=torch.long)
+        starts_host = torch.cat((host.new_zeros(1), host.prod(1).cumsum(0)[:-1]))
+        spatial_shapes = host.to(dev, non_blocking=True)
+        level_start_index = starts_host.to(dev, non_blocking=True)
+        spatial_shapes._ocpg_host = host
+        level_start_index._ocpg_host = starts_host
+        valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
+
+        memory = self.encoder(src, spatial_shapes, level_start_index, valid_ratios, pos, mask)
+
+        b, t, q, c = tgt.shape
+        tgt = tgt.reshape(b * t, q, c)
+        query_pos = query_embed[None].expand(b * t, -1, -1)
+        reference_points = self.reference_points(query_pos).sigmoid()
+        hs, inter_refs, inter_samples = self.decoder(tgt, reference_points, memory, spatial_shapes, level_start_index,
+                                                     valid_ratios, query_pos, mask)
+        feats, start = [], 0
+        for (h, w) in shapes_host[: self.num_feature_level - 1]:
+            feats.append(memory[:, start:start + h * w].reshape(b * t, h, w, c).permute(0, 3, 1, 2).contiguous())
+            start += h * w
+        return hs, feats, reference_points, inter_refs, None, None, inter_samples
+
+
+def build_deforamble_transformer(args):
+    return DeformableTransformer(
+        d_model=args.hidden_dim, nhead=args.nheads, num_encoder_layers=args.enc_layers,
+        num_decoder_layers=args.dec_layers, dim_feedforward=args.dim_feedforward, dropout=args.dropout,
+        activation="relu", return_intermediate_dec=True, num_feature_levels=args.num_feature_levels,
+        dec_n_points=args.dec_n_points, enc_n_points=args.enc_n_points, two_stage=args.two_stage,
+        two_stage_num_proposals=args.num_queries)

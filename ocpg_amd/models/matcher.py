@@ -1,0 +1,111 @@
+"""Query <-> target assignment.  With one referred object per clip the "Hungarian" problem is an argmin over the
+[q,1] cost (reference models/matcher.py:74-171; linear_sum_assignment is imported there but never called).
+
+cost = 2*focal-class + 5*L1 + 2*(-GIoU) + 2*mask-focal + 5*(-dice) (weights from opts.py:88-99); class cost is
+averaged over the VALID frames, box costs over all frames, mask costs over all pixels of the clip.
+The whole batch is one sync-free tensor program (the reference loops over B and T in Python and syncs on
+`tgt_valid[t] == 0`); results are the int64 `src_ind` per clip, identical to the reference's.
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..util.box_ops import box_cxcywh_to_xyxy
+from ..util.misc import nested_tensor_from_tensor_list
+
+
+def _pairwise_giou_1(boxes, tgt):
+    """GIoU of boxes [..., 4] against one target box per leading index, tgt [..., 4] (xyxy), with the reference's
+    +1e-6 smoothing (util/box_ops.py:45-85)."""
+    area_a = (boxes[..., 2] - boxes[..., 0]) * (boxes[..., 3] - boxes[..., 1])
+    area_b = (tgt[..., 2] - tgt[..., 0]) * (tgt[..., 3] - tgt[..., 1])
+    lt = torch.max(boxes[..., :2], tgt[..., :2])
+    rb = torch.min(boxes[..., 2:], tgt[..., 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    union = area_a + area_b - inter
+    iou = (inter + 1e-6) / (union + 1e-6)
+    lt = torch.min(boxes[..., :2], tgt[..., :2])
+    rb = torch.max(boxes[..., 2:], tgt[..., 2:])
+    wh = (rb - lt).clamp(min=0)
+    hull = wh[..., 0] * wh[..., 1]
+    return iou - ((hull - union) + 1e-6) / (hull + 1e-6)
+
+
+def _assert_well_formed(xyxy, what):
+    ok = (xyxy[..., 2:] >= xyxy[..., :2]).all()
+    if xyxy.is_cuda:
+        torch._assert_async(ok, f"error boxes: {what}")
+    else:
+        assert ok, f"error boxes: {what}"
+
+
+class HungarianMatcher(nn.Module):
+    def __init__(self, cost_class: float = 1, cost_bbox: float = 1, cost_giou: float = 1, cost_mask: float = 1,
+                 cost_dice: float = 1, cost_boundary: float = 1, num_classes: int = 1):
+        super().__init__()
+        self.cost_class, self.cost_bbox, self.cost_giou = cost_class, cost_bbox, cost_giou
+        self.cost_mask, self.cost_dice, self.cost_boundary = cost_mask, cost_dice, cost_boundary
+        self.num_classes = num_classes
+        assert cost_class != 0 or cost_bbox != 0 or cost_giou != 0 or cost_mask != 0 or cost_dice != 0, "all costs cant be 0"
+        self.mask_out_stride = 2
+
+    @torch.no_grad()
+    def cost_matrix(self, outputs, targets):
+        """[B, q] matching cost of every query against the clip's single target."""
+        logits, boxes, masks = outputs["pred_logits"], outputs["pred_boxes"], outputs["pred_masks"]
+        bs, nf, nq, h, w = masks.shape
+        gt, _ = nested_tensor_from_tensor_list([t["masks"] for t in targets], size_divisibility=32, split=False).decompose()
+        gt = gt.to(masks)
+        s = self.mask_out_stride
+        im_h, im_w = gt.shape[-2:]
+        gt = gt[:, :, s // 2::s, s // 2::s]
+        assert gt.size(2) * s == im_h and gt.size(3) * s == im_w
+
+        valid = torch.stack([t["valid"] for t in targets]).to(logits.dtype)                  # [B, T]
+        prob = logits.sigmoid()                                                              # [B, T, q, K]
+        alpha, gamma = 0.25, 2.0
+        neg = (1 - alpha) * (prob ** gamma) * (-(1 - prob + 1e-8).log())
+        pos = alpha * ((1 - prob) ** gamma) * (-(prob + 1e-8).log())
+        if self.num_classes == 1:
+            cls = (pos - neg)[..., 0]                                                         # [B, T, q]
+        else:
+            ids = torch.stack([t["labels"] for t in targets])                                # [B, T]
+            cls = torch.gather(pos - neg, 3, ids[:, :, None, None].expand(-1, -1, nq, 1))[..., 0]
+        cost_class = (cls * valid[..., None]).sum(1) / valid.sum(1, keepdim=True)            # mean over valid frames
+
+        tb = torch.stack([t["boxes"] for t in targets]).to(boxes.dtype)                      # [B, T, 4]
+        cost_bbox = (boxes - tb[:, :, None, :]).abs().sum(-1).mean(1)                        # [B, q]
+        pb, tbx = box_cxcywh_to_xyxy(boxes), box_cxcywh_to_xyxy(tb)
+        _assert_well_formed(pb, "predictions")
+        _assert_well_formed(tbx, "targets")
+        cost_giou = -_pairwise_giou_1(pb, tbx[:, :, None, :]).mean(1)
+
+        x = masks.transpose(1, 2).flatten(2)                                                 # [B, q, T*h*w]
+        g = gt.flatten(1)[:, None, :].expand(-1, nq, -1)
+        p = x.sigmoid()
+        ce = F.binary_cross_entropy_with_logits(x, g, reduction="none")
+        p_t = p * g + (1 - p) * (1 - g)
+        focal = (alpha * g + (1 - alpha) * (1 - g)) * ce * ((1 - p_t) ** gamma)
+        cost_mask = focal.mean(2)
+        cost_dice = -((2 * (p * g).sum(2) + 1) / (p.sum(-1) + g.sum(-1) + 1))
+
+        return (self.cost_class * cost_class + self.cost_bbox * cost_bbox + self.cost_giou * cost_giou
+                + self.cost_mask * cost_mask + self.cost_dice * cost_dice)
+
+    @torch.no_grad()
+    def forward(self, outputs, targets):
+        C = self.cost_matrix(outputs, targets)
+        src = C.argmin(dim=1)                                                                # int64 [B]
+        zero = torch.zeros(1, dtype=torch.int64, device=src.device)
+        return [(src[i:i + 1], zero) for i in range(src.shape[0])]
+
+
+def build_matcher(args):
+    if args.binary:
+        num_classes = 1
+    else:
+        num_classes = {"ytvos": 65, "davis": 78, "a2d": 1, "jhmdb": 1}.get(args.dataset_file, 91)
+    return HungarianMatcher(cost_class=args.set_cost_class, cost_bbox=args.set_cost_bbox, cost_giou=args.set_cost_giou,
+                            cost_mask=args.set_cost_mask, cost_dice=args.set_cost_dice,
+                            cost_boundary=args.set_cost_boundary, num_classes=num_classes)

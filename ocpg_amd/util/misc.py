@@ -1,0 +1,109 @@
+"""Host-side helpers of the hot path: NestedTensor, clip padding, inverse_sigmoid, tiny dist helpers.
+
+Mirrors the names the reference's model code imports from util/misc.py (NestedTensor :380-402,
+nested_tensor_from_tensor_list :318-352, nested_tensor_from_videos_list :354-377, inverse_sigmoid :560-564,
+is_dist_avail_and_initialized / get_world_size) -- only what the per-clip path needs; logging, checkpoint
+and all-gather helpers of that file are out of scope.
+"""
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+
+class NestedTensor:
+    """A padded batch plus its boolean padding mask (True = padding)."""
+
+    def __init__(self, tensors: Tensor, mask: Optional[Tensor]):
+        self.tensors = tensors
+        self.mask = mask
+
+    def to(self, device):
+        return NestedTensor(self.tensors.to(device), None if self.mask is None else self.mask.to(device))
+
+    def decompose(self):
+        return self.tensors, self.mask
+
+    def __repr__(self):
+        return f"NestedTensor({tuple(self.tensors.shape)})"
+
+
+def _ceil_to(x: int, m: int) -> int:
+    return (x + m - 1) // m * m if m > 1 else x
+
+
+def nested_tensor_from_tensor_list(tensor_list: List[Tensor], size_divisibility: int = 1, split: bool = True) -> NestedTensor:
+    """Pad a list of [C,H,W] maps (bottom/right, zeros) to a common size; H, W rounded up to `size_divisibility`.
+    With split=True every element is first cut into 3-channel frames (a [T*3,H,W] clip -> T images)."""
+    if split:
+        tensor_list = [frame for t in tensor_list for frame in t.split(3, dim=0)]
+    if tensor_list[0].ndim != 3:
+        raise ValueError("not supported")
+    c = max(t.shape[0] for t in tensor_list)
+    h = _ceil_to(max(t.shape[1] for t in tensor_list), size_divisibility)
+    w = _ceil_to(max(t.shape[2] for t in tensor_list), size_divisibility)
+    ref = tensor_list[0]
+    out = torch.zeros((len(tensor_list), c, h, w), dtype=ref.dtype, device=ref.device)
+    mask = torch.ones((len(tensor_list), h, w), dtype=torch.bool, device=ref.device)
+    for i, t in enumerate(tensor_list):
+        out[i, : t.shape[0], : t.shape[1], : t.shape[2]] = t
+        mask[i, : t.shape[1], : t.shape[2]] = False
+    return NestedTensor(out, mask)
+
+
+def nested_tensor_from_videos_list(videos_list: List[Tensor], size_divisibility: int = 1) -> NestedTensor:
+    """Pad a list of [T,C,H,W] clips to [B,T,C,PH,PW] + mask [B,T,PH,PW]."""
+    t = max(v.shape[0] for v in videos_list)
+    c = max(v.shape[1] for v in videos_list)
+    h = _ceil_to(max(v.shape[2] for v in videos_list), size_divisibility)
+    w = _ceil_to(max(v.shape[3] for v in videos_list), size_divisibility)
+    ref = videos_list[0]
+    out = torch.zeros((len(videos_list), t, c, h, w), dtype=ref.dtype, device=ref.device)
+    mask = torch.ones((len(videos_list), t, h, w), dtype=torch.bool, device=ref.device)
+    for i, v in enumerate(videos_list):
+        out[i, : v.shape[0], :, : v.shape[2], : v.shape[3]] = v
+        mask[i, : v.shape[0], : v.shape[2], : v.shape[3]] = False
+    return NestedTensor(out, mask)
+
+
+def collate_fn(batch):
+    """(clips, targets) pairs -> (NestedTensor padded to /32, tuple of targets); util/misc.py:299-307."""
+    clips, targets = zip(*batch)
+    return nested_tensor_from_videos_list(list(clips), size_divisibility=32), tuple(targets)
+
+
+def inverse_sigmoid(x: Tensor, eps: float = 1e-5) -> Tensor:
+    x = x.clamp(min=0, max=1)
+    return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
+
+
+def is_dist_avail_and_initialized() -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
+def get_world_size() -> int:
+    return dist.get_world_size() if is_dist_avail_and_initialized() else 1
+
+
+def get_rank() -> int:
+    return dist.get_rank() if is_dist_avail_and_initialized() else 0
+
+
+def targets_to(targets, device):
+    skip = {"nouns", "caption", "caption2", "caption3", "dataset_name", "original_id", "image_id"}
+    return [{k: v.to(device) for k, v in t.items() if k not in skip} for t in targets]
+
+
+def reduce_dict(input_dict, average=True):
+    """All-reduce a dict of scalar tensors in ONE collective (util/misc.py:162-186)."""
+    world = get_world_size()
+    if world < 2:
+        return input_dict
+    with torch.no_grad():
+        names = sorted(input_dict.keys())
+        vals = torch.stack([input_dict[k] for k in names], dim=0)
+        dist.all_reduce(vals)
+        if average:
+            vals /= world
+        return dict(zip(names, vals))

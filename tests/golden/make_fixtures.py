@@ -227,6 +227,11 @@ def build_tiny(seed=1, **over):
     model, crit, _ = ref_import.build_reference_model(args, tiny_text(B))
     full = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     model.load_state_dict(synth.synth_state_dict(synth.shapes_of(model), seed=seed))
+    # bernoulli streams cannot be matched across implementations: every dropout (incl. the FeatureResizers'
+    # hard-coded 0.1, ocpg.py:85-94) is disabled on both sides for the parity fixtures
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
     return args, cfg, model, crit, full
 
 
