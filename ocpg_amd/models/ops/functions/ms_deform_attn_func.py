@@ -14,6 +14,44 @@ from torch.autograd.function import once_differentiable
 from ...._lib import check, lib, require_gpu, stream_ptr
 
 
+# -- optional live kernel timing (bench.py): events on the launch stream around every kernel call -----------------
+_TIMING = {"on": False, "events": []}
+
+
+def enable_kernel_timing(on=True):
+    _TIMING["on"] = on
+    _TIMING["events"] = []
+
+
+def collect_kernel_timing():
+    """-> {"fwd_enc": {"ms": total, "n": launches}, ...}; 'enc' = self-attention shape (Lq == S), else 'dec'."""
+    torch.cuda.synchronize()
+    out = {}
+    for key, e0, e1 in _TIMING["events"]:
+        d = out.setdefault(key, {"ms": 0.0, "n": 0})
+        d["ms"] += e0.elapsed_time(e1)
+        d["n"] += 1
+    _TIMING["events"] = []
+    _TIMING["on"] = False
+    return out
+
+
+class _timed:
+    def __init__(self, key):
+        self.key = key
+
+    def __enter__(self):
+        if _TIMING["on"]:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if _TIMING["on"]:
+            self.e1.record()
+            _TIMING["events"].append((self.key, self.e0, self.e1))
+
+
 def _host_shapes(spatial_shapes):
     """Host copy of the [L,2] shapes tensor. Our own transformer attaches it (no sync); foreign callers pay one
     D2H copy -- the reference's module syncs on the same tensor anyway (ms_deform_attn.py:94 assert)."""
@@ -42,7 +80,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     N, S, M, D, L, Lq, P = _dims(value, sampling_loc)
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
     fn = lib().ocpg_msda_fwd_f32 if value.dtype == torch.float32 else lib().ocpg_msda_fwd_f64
-    with torch.cuda.device(value.device):
+    with torch.cuda.device(value.device), _timed("fwd_enc" if Lq == S else "fwd_dec"):
         check(fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
                  attn_weight.data_ptr(), N, S, M, D, L, Lq, P, out.data_ptr(), stream_ptr()), "ocpg_msda_fwd")
     return out
@@ -56,7 +94,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     grad_value = torch.zeros_like(value)
     grad_loc = torch.empty_like(sampling_loc)
     grad_attn = torch.empty_like(attn_weight)
-    with torch.cuda.device(value.device):
+    with torch.cuda.device(value.device), _timed("bwd_enc" if Lq == S else "bwd_dec"):
         if value.dtype == torch.float32:
             hs = _host_shapes(spatial_shapes)
             check(lib().ocpg_msda_bwd_f32(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
