@@ -5,6 +5,22 @@ import torch
 from torch import nn
 
 
+_FREQ_CACHE = {}
+
+
+def _freq(num_pos_feats, temperature, device):
+    """temperature ** (2*(k//2)/feats) as a host-computed constant table.
+
+    Computed with CPU libm and then copied to the device (cached): in padded rows/columns the normalised coordinate
+    is ~ -0.5/1e-6*2pi = -3e6, where a 1-ulp difference between a device `pow` and the host `pow` flips the sine.
+    With a common table the GPU encoding matches the (CPU-generated) reference vectors to fp32 rounding."""
+    key = (num_pos_feats, float(temperature), str(device))
+    if key not in _FREQ_CACHE:
+        k = torch.arange(num_pos_feats, dtype=torch.float32)
+        _FREQ_CACHE[key] = (temperature ** (2 * torch.div(k, 2, rounding_mode="floor") / num_pos_feats)).to(device)
+    return _FREQ_CACHE[key]
+
+
 def _interleave_sin_cos(x):
     """[..., C] -> sin on even / cos on odd feature indices, interleaved back to [..., C]."""
     return torch.stack((x[..., 0::2].sin(), x[..., 1::2].cos()), dim=-1).flatten(-2)
@@ -24,8 +40,7 @@ class PositionEmbeddingSine1D(nn.Module):
         pos = (~mask).cumsum(1, dtype=torch.float32)
         if self.normalize:
             pos = pos / (pos[:, -1:] + 1e-6) * self.scale
-        k = torch.arange(self.num_pos_feats, dtype=torch.float32, device=mask.device)
-        freq = self.temperature ** (2 * torch.div(k, 2, rounding_mode="floor") / self.num_pos_feats)
+        freq = _freq(self.num_pos_feats, self.temperature, mask.device)
         return _interleave_sin_cos(pos[:, :, None] / freq).permute(0, 2, 1)   # [B, C, L]
 
 
@@ -46,8 +61,7 @@ class PositionEmbeddingSine2D(nn.Module):
         if self.normalize:
             y = (y - 0.5) / (y[:, -1:, :] + 1e-6) * self.scale
             x = (x - 0.5) / (x[:, :, -1:] + 1e-6) * self.scale
-        k = torch.arange(self.num_pos_feats, dtype=torch.float32, device=mask.device)
-        freq = self.temperature ** (2 * torch.div(k, 2, rounding_mode="floor") / self.num_pos_feats)
+        freq = _freq(self.num_pos_feats, self.temperature, mask.device)
         px = _interleave_sin_cos(x[..., None] / freq)
         py = _interleave_sin_cos(y[..., None] / freq)
         return torch.cat((py, px), dim=3).permute(0, 3, 1, 2)              # [B, 2*feats, H, W]
