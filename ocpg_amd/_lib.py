@@ -8,7 +8,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libocpg_hip.so")
+# OCPG_HIP_LIB: load another build of the SAME library (kernel experiments / A-B timing); never a fallback path
+LIB_PATH = os.environ.get("OCPG_HIP_LIB") or os.path.join(_HERE, "lib", "libocpg_hip.so")
 _lib = None
 
 _i64p = ctypes.c_void_p

@@ -21,6 +21,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "../../include/ocpg_hip.h"
 
 namespace {
@@ -103,8 +105,10 @@ __global__ __launch_bounds__(256) void msda_fwd_fast(const float* __restrict__ v
   const float* vbase = value + b * (long long)S * MD + m * D + 4 * j;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   const SampleRec* rr = recs + r * NS;
-#pragma unroll 4
-  for (int s = 0; s < NS; ++s) {
+  // (a 4-sample batched, branch-free variant of this loop measured SLOWER on MI355X: 84 vs 64 us at the encoder
+  //  shape -- the gather is L1/TA-throughput bound, not latency bound, and the batch costs occupancy)
+  int s = 0;
+  for (; s < NS; ++s) {
     const SampleRec rec = rr[s];
     if (rec.mask == 0) continue;  // uniform across the row's lanes
     const float hy = 1.f - rec.ly, hx = 1.f - rec.lx;
@@ -210,8 +214,9 @@ __global__ __launch_bounds__(256) void msda_bwd_fast(const float* __restrict__ v
   const long long b = row / ((long long)Lq * M);
   const long long boff = b * (long long)S * MD + m * D + 4 * j;
   const float* vbase = value + boff;
-  float* gbase = gvalue + boff;
+  float* gsc = gvalue + b * (long long)S * MD + m * D + j;
   const float4 go = ld4(gout + row * D + 4 * j);
+  const float gs[4] = {gout[row * D + j], gout[row * D + j + G], gout[row * D + j + 2 * G], gout[row * D + j + 3 * G]};
   const SampleRec* rr = recs + r * NS;
   for (int s = 0; s < NS; ++s) {
     const SampleRec rec = rr[s];
@@ -229,11 +234,9 @@ __global__ __launch_bounds__(256) void msda_bwd_fast(const float* __restrict__ v
       for (int k = 0; k < 4; ++k) {
         if (rec.mask & (1 << k)) {
           const float4 v = ld4(vbase + rec.off00 + offs[k]);
-          float* g = gbase + rec.off00 + offs[k];
-          atomicAdd(g + 0, w[k] * tg.x);
-          atomicAdd(g + 1, w[k] * tg.y);
-          atomicAdd(g + 2, w[k] * tg.z);
-          atomicAdd(g + 3, w[k] * tg.w);
+          float* g = gsc + rec.off00 + offs[k];          // lane j owns channels {j, j+G, j+2G, j+3G}: contiguous 4G-byte segments
+#pragma unroll
+          for (int c = 0; c < 4; ++c) atomicAdd(g + c * G, w[k] * gs[c] * rec.a);
           val.x += w[k] * v.x; val.y += w[k] * v.y; val.z += w[k] * v.z; val.w += w[k] * v.w;
           dxs.x += dxc[k] * v.x; dxs.y += dxc[k] * v.y; dxs.z += dxc[k] * v.z; dxs.w += dxc[k] * v.w;
           dys.x += dyc[k] * v.x; dys.y += dyc[k] * v.y; dys.z += dyc[k] * v.z; dys.w += dyc[k] * v.w;
@@ -250,6 +253,274 @@ __global__ __launch_bounds__(256) void msda_bwd_fast(const float* __restrict__ v
       gattn[row * NS + s] = ga;
       *reinterpret_cast<float2*>(gloc + (row * NS + s) * 2) = make_float2(gx, gy);
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// ---- cross-lane sums inside an 8-lane row group without touching LDS (DPP) ---------------------------------
+__device__ __forceinline__ float dpp_xor1(float v) {   // quad_perm [1,0,3,2]
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_xor2(float v) {   // quad_perm [2,3,0,1]
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_mirror8(float v) {   // row_half_mirror: lane i <-> 7-i inside each 8-lane group
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));
+}
+
+// Sum 4 samples x {ga, gx, gy} over the 8 lanes of a row as a reduce-scatter: after it, the lane pair
+// (j>>1) == s holds sample s's three totals (12 DPP moves instead of 36 LDS-crossbar shuffles).
+// v[s][c] in; returns this lane's sample index, totals in out[0..2].
+__device__ __forceinline__ int reduce_scatter_g8_p4(const float (&v)[4][3], int j, float (&out)[3]) {
+  const bool hi = (j & 4) != 0;          // step 1: partner 7-j (opposite bit 2); keep samples {0,1} (low half) or {2,3}
+  float a[2][3];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float keep = hi ? v[2 + s][c] : v[s][c];
+      const float send = hi ? v[s][c] : v[2 + s][c];
+      a[s][c] = keep + dpp_mirror8(send);
+    }
+  const bool mid = (j & 2) != 0;         // step 2: partner j^2; keep sample 0 or 1 of the pair
+  float b[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float keep = mid ? a[1][c] : a[0][c];
+    const float send = mid ? a[0][c] : a[1][c];
+    b[c] = keep + dpp_xor2(send);
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) out[c] = b[c] + dpp_xor1(b[c]);   // step 3: all-reduce over the last pair
+  return (hi ? 2 : 0) + (mid ? 1 : 0);
+}
+
+// Tiled backward for self-attention over the value's own pixels (Lq == S, the encoder): LDS-privatised grad_value.
+//
+// Float atomics execute at the memory side at ~1.3 TB/s chip-wide (MI355X_MICROARCH.md, "Global float atomics"); the
+// plain scatter above issues 4*L*P*D*4 = 8 KiB of atomic bytes per (query, head) -- 1.67 GB per encoder layer at
+// config #2 -- and is bound by exactly that.  Here one workgroup owns a TILE x TILE patch of query pixels of one
+// level for ONE head.  Neighbouring queries sample neighbouring pixels, so for every destination level the
+// patch's samples fall into a small window whose origin is found from the data (min corner over the patch) and
+// whose size the host derives from the patch extent plus a margin.  Contributions inside the window are summed in
+// LDS (ds_add_f32); the window is flushed once with global atomics (one 128-B segment per pixel and head); anything
+// outside the window falls back to a direct global atomic, so the result never depends on the locality
+// assumption -- only the speed does.
+// The LDS accumulators are DOUBLES: measured on gfx950 (tools/ubench/lds_atomic.hip) a ds_add_f32 wave-instruction
+// costs ~193 cycles per CU (lane-serial), ds_add_f64 ~9, ds_add_u32 ~5 -- f64 is 20x faster than f32 and also makes
+// the in-window sum more accurate than the reference's fp32 atomics; it is rounded to fp32 once at the flush.
+constexpr int kTile = 8;
+constexpr int kMaxTileLevels = 8;
+
+struct TileGeom {
+  int L;
+  int ntiles;                               // tiles per (b, m)
+  int tile_base[kMaxTileLevels + 1];        // first tile id of each query level
+  int tiles_x[kMaxTileLevels];              // tiles per row of each query level
+  int win_w[kMaxTileLevels][kMaxTileLevels];    // [query level][dest level] window width  (pixels)
+  int win_h[kMaxTileLevels][kMaxTileLevels];
+  int win_off[kMaxTileLevels][kMaxTileLevels];  // window start in the LDS accumulator (pixels)
+  int win_pixels[kMaxTileLevels];           // total window pixels of a query level
+};
+
+struct __attribute__((aligned(16))) TileRec {
+  int off00;     // element offset of corner (y0,x0) relative to value[b,0,m,0] (may be virtual)
+  int lvl_mask;  // level << 4 | corner mask
+  float a, ly, lx;
+  int x0, y0;
+  int pad;
+};
+
+template <int G, int NB>
+__global__ __launch_bounds__(256) void msda_bwd_tiled(const float* __restrict__ value, const int64_t* __restrict__ shapes,
+                                                      const int64_t* __restrict__ level_start, const float* __restrict__ loc,
+                                                      const float* __restrict__ attn, const float* __restrict__ gout, int S, int M,
+                                                      int P, TileGeom geo, float* __restrict__ gvalue, float* __restrict__ gloc,
+                                                      float* __restrict__ gattn) {
+  constexpr int D = 4 * G;
+  constexpr int ROWS = 256 / G;                      // queries processed per pass
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int lvlH[kMaxTileLevels], lvlW[kMaxTileLevels], lvlS[kMaxTileLevels];
+  __shared__ int win_ox[kMaxTileLevels], win_oy[kMaxTileLevels];
+  const int L = geo.L;
+  const int NS = L * P;
+  TileRec* recs = reinterpret_cast<TileRec*>(smem);                                  // [ROWS][P]  (one level at a time)
+  double* acc = reinterpret_cast<double*>(smem + (size_t)ROWS * P * sizeof(TileRec));  // [window pixels][D], fp64: see below
+  const int tid = threadIdx.x;
+  if (tid < L) {
+    lvlH[tid] = (int)shapes[2 * tid];
+    lvlW[tid] = (int)shapes[2 * tid + 1];
+    lvlS[tid] = (int)level_start[tid];
+    win_ox[tid] = 0x7fffffff;
+    win_oy[tid] = 0x7fffffff;
+  }
+  // decode (b, m, tile): all uniform
+  int bid = blockIdx.x;
+  const int tile = bid % geo.ntiles;
+  bid /= geo.ntiles;
+  const int m = bid % M;
+  const int b = bid / M;
+  int lq = 0;
+  while (lq + 1 < L && tile >= geo.tile_base[lq + 1]) ++lq;
+  const int t_in = tile - geo.tile_base[lq];
+  const int ty0 = (t_in / geo.tiles_x[lq]) * kTile, tx0 = (t_in % geo.tiles_x[lq]) * kTile;
+  __syncthreads();
+  const int Hq = lvlH[lq], Wq = lvlW[lq], Sq = lvlS[lq];
+  const int th = min(kTile, Hq - ty0), tw = min(kTile, Wq - tx0);
+  const int nq = th * tw;                                                 // queries in this tile (<= 64)
+  const int MD = M * D;
+
+  // pass A: window origins = min (y0, x0) over the tile's valid samples, per destination level
+  for (int i = tid; i < nq * NS; i += 256) {
+    const int qi = i / NS, s = i % NS, l = s / P;
+    const int q = Sq + (ty0 + qi / tw) * Wq + tx0 + qi % tw;
+    const long long row = ((long long)b * S + q) * M + m;
+    const float2 xy = *reinterpret_cast<const float2*>(loc + (row * NS + s) * 2);
+    const int H = lvlH[l], W = lvlW[l];
+    const float h_im = xy.y * (float)H - 0.5f, w_im = xy.x * (float)W - 0.5f;
+    if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+      atomicMin(&win_oy[l], max((int)floorf(h_im), 0));
+      atomicMin(&win_ox[l], max((int)floorf(w_im), 0));
+    }
+  }
+  __syncthreads();
+
+  const int r = tid / G, j = tid % G;
+  const long long boff = (long long)b * S * MD + m * D + 4 * j;
+  for (int l = 0; l < L; ++l) {                      // one destination level at a time: one LDS window live
+    const int H = lvlH[l], W = lvlW[l];
+    const int ww = geo.win_w[lq][l], wh = geo.win_h[lq][l];
+    const int ox = (win_ox[l] == 0x7fffffff) ? 0 : max(0, min(win_ox[l], W - ww));   // keep the window inside the map
+    const int oy = (win_oy[l] == 0x7fffffff) ? 0 : max(0, min(win_oy[l], H - wh));
+    const int rowstride = W * MD;
+    const float* vbase = value + boff + (long long)lvlS[l] * MD;
+    float* gvalue_l = gvalue + (long long)b * S * MD + m * D + (long long)lvlS[l] * MD;
+    for (int i = tid; i < ww * wh * D; i += 256) acc[i] = 0.0;
+    for (int q0 = 0; q0 < nq; q0 += ROWS) {
+      const int nrow = min(ROWS, nq - q0);
+      for (int i = tid; i < nrow * P; i += 256) {     // records of this pass: P samples per query
+        const int rr_ = i / P, p = i % P, qi = q0 + rr_;
+        const int q = Sq + (ty0 + qi / tw) * Wq + tx0 + qi % tw;
+        const long long row = ((long long)b * S + q) * M + m;
+        const int s = l * P + p;
+        const float2 xy = *reinterpret_cast<const float2*>(loc + (row * NS + s) * 2);
+        const float h_im = xy.y * (float)H - 0.5f, w_im = xy.x * (float)W - 0.5f;
+        TileRec rec;
+        rec.a = attn[row * NS + s];
+        rec.pad = 0;
+        if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+          const int y0 = (int)floorf(h_im), x0 = (int)floorf(w_im);
+          rec.ly = h_im - (float)y0;
+          rec.lx = w_im - (float)x0;
+          const bool y0ok = y0 >= 0, y1ok = y0 + 1 <= H - 1, x0ok = x0 >= 0, x1ok = x0 + 1 <= W - 1;
+          rec.lvl_mask = (y0ok && x0ok ? 1 : 0) | (y0ok && x1ok ? 2 : 0) | (y1ok && x0ok ? 4 : 0) | (y1ok && x1ok ? 8 : 0);
+          rec.off00 = (y0 * W + x0) * MD;
+          rec.x0 = x0;
+          rec.y0 = y0;
+        } else {
+          rec.ly = rec.lx = 0.f;
+          rec.lvl_mask = 0;
+          rec.off00 = 0;
+          rec.x0 = rec.y0 = 0;
+        }
+        recs[i] = rec;
+      }
+      __syncthreads();
+      if (r < nrow) {     // whole G-lane groups take the branch together
+        const int qi = q0 + r;
+        const int q = Sq + (ty0 + qi / tw) * Wq + tx0 + qi % tw;
+        const long long row = ((long long)b * S + q) * M + m;
+        const float4 go = ld4(gout + row * D + 4 * j);
+        const float gs[4] = {gout[row * D + j], gout[row * D + j + G], gout[row * D + j + 2 * G], gout[row * D + j + 3 * G]};
+        const TileRec* rr = recs + r * P;
+        const int offs[4] = {0, MD, rowstride, rowstride + MD};
+        for (int p0 = 0; p0 < P; p0 += NB) {
+          TileRec rec[NB];
+          float4 v[NB][4];
+          float red[NB][3];
+#pragma unroll
+          for (int i = 0; i < NB; ++i) rec[i] = rr[p0 + i];
+#pragma unroll
+          for (int i = 0; i < NB; ++i)      // all corner loads of the batch in flight before the first use
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[i][k] = ld4((rec[i].lvl_mask & (1 << k)) ? vbase + rec[i].off00 + offs[k] : vbase);
+#pragma unroll
+          for (int i = 0; i < NB; ++i) {
+            const int mask = rec[i].lvl_mask;
+            const float hy = 1.f - rec[i].ly, hx = 1.f - rec[i].lx;
+            const float w[4] = {hy * hx, hy * rec[i].lx, rec[i].ly * hx, rec[i].ly * rec[i].lx};
+            const float dyc[4] = {-hx, -rec[i].lx, hx, rec[i].lx};
+            const float dxc[4] = {-hy, hy, -rec[i].ly, rec[i].ly};
+            const float a = mask ? rec[i].a : 0.f;
+            const float4 tg = make_float4(go.x * a, go.y * a, go.z * a, go.w * a);
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 dxs = val, dys = val;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              if (mask & (1 << k)) {
+                const float4 vv = v[i][k];
+                const int px = rec[i].x0 + (k & 1) - ox, py = rec[i].y0 + (k >> 1) - oy;
+                // scatter: lane j owns channels {j, j+G, j+2G, j+3G} here, so one atomic instruction covers G
+                // CONSECUTIVE floats per row (contiguous 4G-byte segments in memory, G consecutive LDS banks)
+                if (px >= 0 && px < ww && py >= 0 && py < wh) {      // inside the privatised window: ds_add_f32
+                  const int pp = py * ww + px;
+                  double* gl_ = acc + pp * D + j;                     // bank-group swizzle: channel group i sits in slot (i+pp)&3
+#ifndef EXP_NO_LDS_ATOMIC
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) atomicAdd(gl_ + ((c + pp) & 3) * G, (double)(w[k] * gs[c] * a));   // ds_add_f64
+#else
+                  asm volatile("" ::"v"(gl_), "v"(w[k] * gs[0] * a));
+#endif
+                } else {                                              // outside: straight to memory
+                  float* g = gvalue_l + rec[i].off00 + offs[k] + j;
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) atomicAdd(g + c * G, w[k] * gs[c] * a);
+                }
+                val.x += w[k] * vv.x; val.y += w[k] * vv.y; val.z += w[k] * vv.z; val.w += w[k] * vv.w;
+                dxs.x += dxc[k] * vv.x; dxs.y += dxc[k] * vv.y; dxs.z += dxc[k] * vv.z; dxs.w += dxc[k] * vv.w;
+                dys.x += dyc[k] * vv.x; dys.y += dyc[k] * vv.y; dys.z += dyc[k] * vv.z; dys.w += dyc[k] * vv.w;
+              }
+            }
+            red[i][0] = mask ? go.x * val.x + go.y * val.y + go.z * val.z + go.w * val.w : 0.f;
+            red[i][1] = (float)W * (dxs.x * tg.x + dxs.y * tg.y + dxs.z * tg.z + dxs.w * tg.w);
+            red[i][2] = (float)H * (dys.x * tg.x + dys.y * tg.y + dys.z * tg.z + dys.w * tg.w);
+          }
+          if constexpr (G == 8 && NB == 4) {
+            float tot[3];
+            const int sidx = reduce_scatter_g8_p4(red, j, tot);
+            if ((j & 1) == 0) {
+              const long long wi = row * NS + l * P + p0 + sidx;
+              gattn[wi] = tot[0];
+              *reinterpret_cast<float2*>(gloc + wi * 2) = make_float2(tot[1], tot[2]);
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+              const float ga = group_sum<G>(red[i][0]), gx = group_sum<G>(red[i][1]), gy = group_sum<G>(red[i][2]);
+              if (j == 0) {
+                const long long wi = row * NS + l * P + p0 + i;
+                gattn[wi] = ga;
+                *reinterpret_cast<float2*>(gloc + wi * 2) = make_float2(gx, gy);
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    // flush this level's window: one global atomic per touched (pixel, channel)
+    float* gl = gvalue + (long long)b * S * MD + (long long)lvlS[l] * MD + m * D;
+    for (int i = tid; i < ww * wh * D; i += 256) {
+      const float v = (float)acc[i];
+      if (v != 0.f) {
+        const int pp = i / D, slot = (i % D) / G, jj = i % G;
+        const int c = jj + G * ((slot - pp) & 3);                  // undo the bank-group swizzle
+#ifndef EXP_NO_FLUSH
+        atomicAdd(gl + ((long long)(oy + pp / ww) * W + ox + pp % ww) * MD + c, v);
+#endif
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -325,6 +596,44 @@ __global__ __launch_bounds__(256) void msda_bwd_generic(const T* __restrict__ va
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Host side of the tiled backward: window sizes per (query level, destination level) from the level shapes.
+// margin: how far (in destination pixels) beyond the patch's own footprint the window extends; the origin is
+// data-driven, so the margin only has to cover the SPREAD of the offsets, not their common shift.
+inline bool make_tile_geom(const int64_t* sh, int L, int D, int rows_per_pass, int P, TileGeom& g, size_t& lds_bytes) {
+  const int margin = 3;
+  const size_t cap = 52 * 1024;                       // LDS budget per workgroup -> 3 workgroups (12 waves) per CU
+  const size_t rec_bytes = (size_t)rows_per_pass * P * sizeof(TileRec);
+  g.L = L;
+  int base = 0;
+  int max_pix = 0;
+  for (int lq = 0; lq < L; ++lq) {
+    const int Hq = (int)sh[2 * lq], Wq = (int)sh[2 * lq + 1];
+    if (Hq <= 0 || Wq <= 0) return false;
+    g.tile_base[lq] = base;
+    g.tiles_x[lq] = (Wq + kTile - 1) / kTile;
+    base += g.tiles_x[lq] * ((Hq + kTile - 1) / kTile);
+    int off = 0;
+    for (int l = 0; l < L; ++l) {
+      const int H = (int)sh[2 * l], W = (int)sh[2 * l + 1];
+      const int fw = (std::min(kTile, Wq) * W + Wq - 1) / Wq, fh = (std::min(kTile, Hq) * H + Hq - 1) / Hq;   // patch footprint
+      int ww = std::min(W, fw + 2 * margin + 2), wh = std::min(H, fh + 2 * margin + 2);
+      while ((size_t)ww * wh * D * sizeof(double) + rec_bytes > cap) {     // shrink to the budget (more fallback atomics, same result)
+        if (ww >= wh && ww > 1) --ww; else if (wh > 1) --wh; else return false;
+      }
+      g.win_w[lq][l] = ww;
+      g.win_h[lq][l] = wh;
+      g.win_off[lq][l] = 0;
+      off += ww * wh;
+      max_pix = std::max(max_pix, ww * wh);
+    }
+    g.win_pixels[lq] = off;
+  }
+  g.tile_base[L] = base;
+  g.ntiles = base;
+  lds_bytes = rec_bytes + (size_t)max_pix * D * sizeof(double);
+  return lds_bytes <= cap;
+}
+
 inline int fast_group(int D) {
   if (D % 4) return 0;
   const int g = D / 4;
@@ -408,7 +717,6 @@ int ocpg_msda_bwd_f32(const float* value, const int64_t* shapes, const int64_t* 
                       const float* grad_out, int N, int S, int M, int D, int L, int Lq, int P, float* grad_value, float* grad_loc,
                       float* grad_attn, const int64_t* shapes_host, void* stream) {
   if (int e = check_common(value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P)) return e;
-  (void)shapes_host;
   const long long rows = (long long)N * Lq * M;
   if (rows == 0) return 0;
   if (!grad_out) return -1013;
@@ -420,6 +728,21 @@ int ocpg_msda_bwd_f32(const float* value, const int64_t* shapes, const int64_t* 
   const size_t rec_bytes = (size_t)L * P * sizeof(SampleRec);
   if (G && L <= kMaxLevels && (256 / G) * rec_bytes <= 48 * 1024 && (long long)S * M * D < (1LL << 31)) {
     const int rpb = 256 / G;
+    TileGeom geo;
+    size_t tiled_lds = 0;
+    if (shapes_host && Lq == S && L <= kMaxTileLevels && G >= 4 && G <= 16 && make_tile_geom(shapes_host, L, D, rpb, P, geo, tiled_lds)) {
+      const unsigned grid = (unsigned)((long long)N * M * geo.ntiles);
+      const size_t lds = tiled_lds;
+#define TILED_LAUNCH(G_, NB_) msda_bwd_tiled<G_, NB_><<<grid, 256, lds, st>>>(value, shapes, level_start, loc, attn, grad_out, S, M, P, geo, grad_value, grad_loc, grad_attn)
+      const bool b4 = (P % 4) == 0;
+      switch (G) {
+        case 4: if (b4) TILED_LAUNCH(4, 4); else TILED_LAUNCH(4, 1); break;
+        case 8: if (b4) TILED_LAUNCH(8, 4); else TILED_LAUNCH(8, 1); break;
+        default: if (b4) TILED_LAUNCH(16, 4); else TILED_LAUNCH(16, 1); break;
+      }
+#undef TILED_LAUNCH
+      return launch_status();
+    }
     const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
     const size_t lds = rpb * rec_bytes;
     FAST_DISPATCH(G, msda_bwd_fast, value, shapes, level_start, loc, attn, grad_out, S, M, L, Lq, P, rows, grad_value, grad_loc,

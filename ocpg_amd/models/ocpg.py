@@ -30,6 +30,7 @@ from .matcher import build_matcher
 from .modules import LFMResizeAdaptive
 from .position_encoding import PositionEmbeddingSine1D
 from .postprocessors import build_postprocessors
+from .resample import bicubic_resize
 from .segmentation import VisionLanguageFusionModule
 from .text_encoder.text_encoder import FeatureResizer, PrecomputedText, TextEncoder
 
@@ -258,7 +259,7 @@ class OCPG(nn.Module):
 
         # ---- dynamic-conv mask head ----
         tar = memory[0].shape[-2:]
-        memory_fusion = sum(F.interpolate(x, size=tar, mode="bicubic", align_corners=False) for x in memory)
+        memory_fusion = sum(bicubic_resize(x.float(), tar) for x in memory)
         mask_features = memory_fusion.unflatten(0, (b, t))                         # [b, t, C, h, w]
         seg_masks, seg_masks_shuffled = [], []
         for lvl in range(nl):
