@@ -1,0 +1,160 @@
+"""N>1 path on CPU: 2 ranks over gloo, DistributedDataParallel around the product model (MSDA op -> test double),
+each rank a different clip.  Checks (a) DDP-averaged gradients equal the average of the two single-process gradients
+(which also exercises the criterion's num_boxes all-reduce + /world_size), (b) every trainable parameter received a
+gradient, so find_unused_parameters=False (as bench.py uses) is legitimate; test_num_boxes_allreduce covers unequal
+valid-frame counts across ranks."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _setup_paths():
+    for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _build(meta):
+    import model_checks
+    import ocpg_amd.models.ops.modules.ms_deform_attn as mod
+    from oracle.msda import MSDAOracleFunction
+    mod.MSDeformAttnFunction = MSDAOracleFunction
+    return model_checks.build_product(meta, torch.device("cpu"))
+
+
+def _clip_grads(rank_clip, meta, model, crit, ddp=None):
+    import cases
+    import model_checks
+    from ocpg_amd.util.misc import NestedTensor
+    T, H, W = meta["T"], meta["H"], meta["W"]
+    x, mask, targets = cases.e2e_inputs(2, T, H, W, meta["nopad_sizes"])
+    x, mask, targets = x[rank_clip:rank_clip + 1], mask[rank_clip:rank_clip + 1], targets[rank_clip:rank_clip + 1]
+    f, s, m = cases.tiny_text(2)
+    from ocpg_amd.models.text_encoder.text_encoder import PrecomputedText
+    text = PrecomputedText(f[rank_clip:rank_clip + 1], s[rank_clip:rank_clip + 1], m[rank_clip:rank_clip + 1])
+    net = ddp or model
+    model.train(), crit.train()
+    crit.iter = 0            # the level-set warm-up weight depends on the criterion's call counter
+    model.zero_grad(set_to_none=True)
+    out = net(NestedTensor(x, mask), text, targets)
+    losses, *_ = crit(out, targets)
+    total = sum(losses[k] * crit.weight_dict[k] for k in losses if k in crit.weight_dict)
+    total.backward()
+    return {k: (p.grad.clone() if p.grad is not None else None) for k, p in model.named_parameters()}, total.item()
+
+
+def _worker(rank, world, port, q):
+    _setup_paths()
+    torch.set_num_threads(2)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from conftest import Golden
+    meta = Golden("e2e_tiny").meta
+    _, model, crit = _build(meta)
+    ddp = torch.nn.parallel.DistributedDataParallel(model, find_unused_parameters=False)
+    grads, total = _clip_grads(rank, meta, model, crit, ddp)
+    q.put((rank, {k: (None if g is None else g.numpy()) for k, g in grads.items()}, total))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_ddp_two_ranks_gloo():
+    _setup_paths()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        r, g, t = q.get(timeout=500)
+        got[r] = (g, t)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # DDP leaves identical (averaged) grads on both ranks
+    for k in got[0][0]:
+        a, b = got[0][0][k], got[1][0][k]
+        assert (a is None) == (b is None), k
+        if a is not None:
+            assert abs(a - b).max() <= 1e-6 * (abs(a).max() + 1e-12) + 1e-9, k
+    # single-process reference: the same two clips one after the other; DDP must have left their AVERAGE
+    from conftest import Golden
+    meta = Golden("e2e_tiny").meta
+    _, model, crit = _build(meta)
+    singles = [_clip_grads(r, meta, model, crit)[0] for r in range(2)]
+    n_checked = 0
+    for k, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        a = got[0][0][k]
+        assert a is not None, f"{k} got no gradient under DDP (find_unused_parameters=False would break)"
+        want = 0.5 * (singles[0][k] + singles[1][k]).numpy()
+        assert abs(a - want).max() <= 2e-4 * (abs(want).max() + 1e-12) + 1e-7, k
+        n_checked += 1
+    assert n_checked > 100
+
+
+def _nb_worker(rank, world, port, q):
+    _setup_paths()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import module_checks as mc
+    from conftest import Golden
+    g = Golden("matcher_crit")
+    # rank 0 has 3 valid frames in its batch, rank 1 has 1 -> num_boxes = (3 + 1) / 2 = 2 on both
+    import cases, synth
+    from ocpg_amd.models import build_model
+    m = g.meta
+    _, crit, _ = build_model(cases.default_args(**m["cfg"]))
+    b, t, H, W = m["b"], m["t"], m["H"], m["W"]
+    targets = synth.synthetic_targets(b, t, H, W)
+    targets[1]["valid"] = torch.tensor([1, 0]) if rank == 0 else torch.tensor([0, 0])
+    targets[0]["valid"] = torch.tensor([1, 1]) if rank == 0 else torch.tensor([1, 0])
+    out = {"pred_logits": synth.rand("mc_logits", (b, t, m["q"], 1)), "pred_boxes": synth.rand("mc_boxes", (b, t, m["q"], 4), uniform=True) * 0.5 + 0.2}
+    idx = [(torch.tensor([0]), torch.tensor([0])) for _ in range(b)]
+    nb = torch.stack([tt["valid"] for tt in targets]).sum().float().reshape(1)
+    dist.all_reduce(nb)
+    expect = (nb / world).clamp(min=1)[0]
+    crit.losses = ["boxes"]
+    out.update(main_matcher_index=idx, aux_matcher_index=[], pred_masks_low=out["pred_logits"])
+    losses, *_ = crit(out, targets)
+    sel = out["pred_boxes"][torch.arange(b), :, 0].reshape(-1, 4)
+    tb = torch.cat([tt["boxes"] for tt in targets])
+    q.put((rank, float(losses["loss_bbox"]), float((sel - tb).abs().sum() / expect), float(expect)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_num_boxes_allreduce():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nb_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=200) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, got, want, nb in res:
+        assert nb == 2.0
+        assert abs(got - want) <= 1e-6 * abs(want)
