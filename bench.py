@@ -69,19 +69,144 @@ def make_optimizer(model, args):
     return torch.optim.AdamW(groups, lr=args.lr, weight_decay=args.weight_decay, fused=True)
 
 
-def train_step(model, criterion, optimizer, make_samples, text, targets, args, amp_dtype):
-    """engine.py:46-113 for one batch (logging all-reduce and .item() syncs left out of the hot loop)."""
+def forward_backward(model, criterion, samples, text, targets, amp_dtype, num_boxes=None, keep=None):
+    """engine.py:50-62 + backward: forward, criterion, weighted sum, backward (grads accumulate into .grad)."""
     with torch.autocast(device_type="cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
-        out = model(make_samples(), text, targets)
+        out = model(samples, text, targets)
+        if num_boxes is not None:
+            out["num_boxes"] = num_boxes
         loss_dict, *_ = criterion(out, targets)
         wd = criterion.weight_dict
         loss = sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)
-    optimizer.zero_grad(set_to_none=True)
     loss.backward()
-    if args.clip_max_norm > 0:
-        torch.nn.utils.clip_grad_norm_(model.parameters(), args.clip_max_norm, error_if_nonfinite=False, foreach=True)
-    optimizer.step()
-    return loss
+    if keep is not None:        # static graph outputs (the usual whole-network-capture rule: keep them referenced)
+        keep.update(out=out, loss_dict=loss_dict, loss=loss)
+    return loss.detach()
+
+
+class EagerStep:
+    """engine.py:46-113 for one batch, eager launches (DDP overlaps the gradient all-reduce with backward)."""
+
+    def __init__(self, model, ddp_model, criterion, optimizer, make_samples, text, targets, args, amp_dtype):
+        self.__dict__.update(locals())
+
+    def __call__(self):
+        self.optimizer.zero_grad(set_to_none=True)
+        loss = forward_backward(self.ddp_model, self.criterion, self.make_samples(), self.text, self.targets, self.amp_dtype)
+        if self.args.clip_max_norm > 0:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.args.clip_max_norm, error_if_nonfinite=False, foreach=True)
+        self.optimizer.step()
+        return loss
+
+
+class GraphStep:
+    """Same step with forward + criterion + backward captured once into a HIP graph and replayed (launch-bound inner
+    loop: ~9 500 kernels per step).  Outside the graph, per step: copy the batch into the static input buffers, the
+    criterion's num_boxes all-reduce, (N>1) one flat gradient all-reduce over RCCL, grad clip, AdamW."""
+
+    def __init__(self, model, criterion, optimizer, make_samples, text, targets, args, amp_dtype, world):
+        from ocpg_amd.util.misc import NestedTensor
+        self.model, self.criterion, self.optimizer, self.args, self.world = model, criterion, optimizer, args, world
+        self.make_samples, self.targets = make_samples, targets
+        first = make_samples()
+        self.x, self.mask = first.tensors.clone(), first.mask.clone()
+        self.num_boxes = criterion.global_num_boxes(targets, self.x.device).clone()
+        criterion.iter_device = torch.zeros((), device=self.x.device)       # the criterion's call counter, device-resident
+        self.calls_per_fwd = args.dec_layers
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):                      # warm-up on the capture stream: MIOpen find, FFT plans, workspaces
+                optimizer.zero_grad(set_to_none=True)
+                forward_backward(model, criterion, NestedTensor(self.x.clone(), self.mask.clone()), text, targets, amp_dtype, self.num_boxes)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        optimizer.zero_grad(set_to_none=True)
+        self.graph = torch.cuda.CUDAGraph()
+        # The captured step's outputs (model outputs, the 36 losses and through them the autograd graph) stay referenced
+        # for the lifetime of the graph.  Measured on ROCm 7.2 / torch 2.10: letting them die inside the capture made
+        # the THIRD replay return NaN gradients (tools/dbg_graph2.py, KEEP=... bisect); with them alive replays match
+        # eager.  self.check() compares a replay against an eager step before the timed region.
+        self.static = {}
+        with torch.cuda.graph(self.graph):
+            self.loss = forward_backward(model, criterion, NestedTensor(self.x.clone(), self.mask.clone()), text, targets, amp_dtype,
+                                         self.num_boxes, keep=self.static)
+        self.grads = [p.grad for p in self.params]
+        assert all(g is not None for g in self.grads), "a trainable parameter received no gradient"
+        self.flat = None
+
+    def check(self, eager_loss, rtol=0.25):
+        """One replay (no optimizer step) against the eager loss of the warm-up steps: finite, same ballpark (dropout
+        masks differ), every gradient finite."""
+        self.graph.replay()
+        torch.cuda.synchronize()
+        loss = float(self.loss)
+        ok = loss == loss and abs(loss - eager_loss) <= rtol * abs(eager_loss) and all(bool(torch.isfinite(g).all()) for g in self.grads)
+        if not ok:
+            raise RuntimeError(f"graph replay disagrees with eager: {loss} vs {eager_loss}")
+
+    def __call__(self):
+        s = self.make_samples()
+        self.x.copy_(s.tensors), self.mask.copy_(s.mask)
+        self.num_boxes.copy_(self.criterion.global_num_boxes(self.targets, self.x.device))
+        # Host-side fences around the replay: on ROCm 7.2 a replay that is merely stream-ordered against the eager
+        # optimizer kernels before/after it produced NaN gradients after a few steps (tools/dbg_graph2.py: stable with a
+        # synchronize per iteration, unstable without).  Two stream syncs cost ~50 us of a ~70 ms step.
+        torch.cuda.synchronize()
+        self.graph.replay()
+        torch.cuda.synchronize()
+        self.criterion.iter_device += self.calls_per_fwd
+        if self.world > 1:
+            flat = torch._utils._flatten_dense_tensors(self.grads)
+            dist.all_reduce(flat)
+            flat.div_(self.world)
+            torch._foreach_copy_(self.grads, list(torch._utils._unflatten_dense_tensors(flat, self.grads)))
+        if self.args.clip_max_norm > 0:
+            torch.nn.utils.clip_grad_norm_(self.params, self.args.clip_max_norm, error_if_nonfinite=False, foreach=True)
+        self.optimizer.step()
+        return self.loss
+
+
+def time_msda_kernels(n_frames, device, iters=20):
+    """Live HIP-event timing of the MSDeformAttn kernels at the encoder / decoder shapes of this run, on the launch
+    stream (used when the step itself is a graph replay, where per-kernel events cannot be interleaved)."""
+    from ocpg_amd.models.ops.functions import ms_deform_attn_func as f
+    shapes_l = [(HEIGHT // 8 >> i, WIDTH // 8 >> i) for i in range(4)]
+    shapes = torch.tensor(shapes_l, dtype=torch.long)
+    ls = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    S = int(shapes.prod(1).sum())
+    sh, lsd = shapes.to(device), ls.to(device)
+    sh._ocpg_host = shapes
+    g = torch.Generator().manual_seed(0)
+    out = {}
+    for tag, Lq in (("enc", S), ("dec", 5)):
+        value = torch.randn(n_frames, S, 8, 32, generator=g).to(device)
+        if Lq == S:      # the model's own pattern at init: reference point = the pixel itself, ring offsets of 1..4 px
+            import math
+            refs = []
+            for (h, w) in shapes_l:
+                ys, xs = torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing="ij")
+                refs.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], -1))
+            ref = torch.cat(refs, 0)[None, :, None, None, None, :]
+            th = torch.arange(8) * (2 * math.pi / 8)
+            ring = torch.stack([th.cos(), th.sin()], -1)
+            ring = (ring / ring.abs().max(-1, keepdim=True)[0]).view(1, 1, 8, 1, 1, 2) * torch.arange(1, 5).view(1, 1, 1, 1, 4, 1)
+            norm = torch.tensor([[w, h] for h, w in shapes_l], dtype=torch.float32).view(1, 1, 1, 4, 1, 2)
+            loc = (ref + ring / norm).expand(n_frames, S, 8, 4, 4, 2).contiguous().to(device)
+        else:
+            loc = torch.rand(n_frames, Lq, 8, 4, 4, 2, generator=g).to(device)
+        attn = torch.softmax(torch.randn(n_frames, Lq, 8, 16, generator=g), -1).view(n_frames, Lq, 8, 4, 4).to(device)
+        go = torch.randn(n_frames, Lq, 256, generator=g).to(device)
+        for _ in range(3):
+            f.ms_deform_attn_forward(value, sh, lsd, loc, attn)
+            f.ms_deform_attn_backward(value, sh, lsd, loc, attn, go)
+        f.enable_kernel_timing(True)
+        for _ in range(iters):
+            f.ms_deform_attn_forward(value, sh, lsd, loc, attn)
+            f.ms_deform_attn_backward(value, sh, lsd, loc, attn, go)
+        out.update(f.collect_kernel_timing())
+    return out
 
 
 def cpu_baseline(sample_frames=T_FRAMES):
@@ -103,6 +228,11 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="EXPERIMENTAL: replay forward+criterion+backward as one HIP graph. Off by default: on ROCm 7.2 / "
+                         "torch 2.10 replays turn non-finite after the first optimizer step unless extra tensors are kept "
+                         "alive (memory-reuse hazard inside the captured graph, see DESIGN.md section 5); the self-check below "
+                         "falls back to eager when that happens.")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,12 +258,32 @@ def main():
     criterion.to(device)
     model.train(), criterion.train()
     optimizer = make_optimizer(model, args)
-    step_model = model
-    if world > 1:
-        step_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], gradient_as_bucket_view=True,
-                                                               bucket_cap_mb=64, find_unused_parameters=False)
     amp_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}[a.dtype]
     make_samples, text, targets = synthetic_batch(a.clips_per_gpu, device, seed=42 + rank)
+    step, mode = None, "eager"
+    if a.graph:
+        try:
+            torch.manual_seed(1234 + rank)
+            model.zero_grad(set_to_none=True)
+            eager_loss = float(forward_backward(model, criterion, make_samples(), text, targets, amp_dtype))
+            model.zero_grad(set_to_none=True)
+            criterion.iter = 0
+            step = GraphStep(model, criterion, optimizer, make_samples, text, targets, args, amp_dtype, world)
+            step.check(eager_loss)
+            for _ in range(3):          # the instability shows after optimizer steps: exercise them before trusting the graph
+                if not bool(torch.isfinite(step())):
+                    raise RuntimeError("graph replay turned non-finite after an optimizer step")
+            mode = "hipgraph(fwd+criterion+bwd)"
+        except Exception as e:      # capture is an optimisation, never a requirement: report and run eagerly
+            print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {str(e)[:200]}); running eagerly", file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+            optimizer.zero_grad(set_to_none=True)
+    if step is None:
+        ddp_model = model
+        if world > 1:
+            ddp_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], gradient_as_bucket_view=True,
+                                                                  bucket_cap_mb=64, find_unused_parameters=False)
+        step = EagerStep(model, ddp_model, criterion, optimizer, make_samples, text, targets, args, amp_dtype)
 
     def sync():
         if world > 1:
@@ -141,21 +291,27 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
-        train_step(step_model, criterion, optimizer, make_samples, text, targets, args, amp_dtype)
+        step()
     sync()
-    if not a.no_kernel_timing:
+    if not a.no_kernel_timing and mode == "eager":
         msda_fn.enable_kernel_timing(True)
     t0 = time.perf_counter()
+    losses = []
     for _ in range(a.steps):
-        loss = train_step(step_model, criterion, optimizer, make_samples, text, targets, args, amp_dtype)
+        loss = step()
+        losses.append(loss.clone())
     sync()
     dt = time.perf_counter() - t0
+    if not all(bool(torch.isfinite(l)) for l in losses):
+        raise AssertionError("non-finite loss during the timed steps: " + " ".join(f"{float(l):.2f}" for l in losses))
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = t.item()
-    kt = msda_fn.collect_kernel_timing() if not a.no_kernel_timing else {}
+    kt = msda_fn.collect_kernel_timing() if (not a.no_kernel_timing and mode == "eager") else {}
     assert torch.isfinite(loss).item(), "non-finite loss"
+    if not a.no_kernel_timing and mode != "eager" and rank == 0:
+        kt = time_msda_kernels(a.clips_per_gpu * T_FRAMES, device)
 
     clips = a.steps * a.clips_per_gpu * world
     line = {
@@ -165,8 +321,8 @@ def main():
         "config": {"workload": f"{a.backbone} + 4-scale deformable transformer (4 enc + 4 dec), {T_FRAMES}x{HEIGHT}x{WIDTH} clips, "
                                f"5 queries, {a.clips_per_gpu} clips/GPU/step, step = fwd + criterion + bwd + clip + AdamW",
                    "global_batch": a.clips_per_gpu * world, "parallelism": f"dp{world}", "weights": "random init",
-                   "text": "random features [B,9,768] (RoBERTa bypassed, BASELINE configs #1-#4)"},
-        "final_loss": float(loss),
+                   "text": "random features [B,9,768] (RoBERTa bypassed, BASELINE configs #1-#4)", "launch": mode},
+        "final_loss": float(loss.detach()),
     }
     if rank == 0:
         key = "bwd_enc"

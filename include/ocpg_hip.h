@@ -60,6 +60,19 @@ int ocpg_msda_bwd_f64(const double* value, const int64_t* shapes, const int64_t*
                       int N, int S, int M, int D, int L, int Lq, int P,
                       double* grad_value, double* grad_loc, double* grad_attn, void* stream);
 
+/* Fused frozen-BatchNorm affine (+ residual) (+ ReLU) over a feature map -- replaces the per-BN elementwise chain of
+ * FrozenBatchNorm2d.forward (models/backbone.py:46-56: x*scale + bias with scale = w*rsqrt(var+1e-5)) followed by
+ * torchvision Bottleneck's "out += identity" / ReLU.  scale/shift are the per-channel fp32 vectors [C].
+ *   y[o,c,i] = act(x[o,c,i] * scale[c] + shift[c] (+ skip[o,c,i])),  element (o,c,i) at ((o*C + c)*inner + i)
+ *   NHWC / channels_last: n_outer = N*H*W, inner = 1;   NCHW: n_outer = N, inner = H*W.
+ * dtype: 0 = float32, 1 = bfloat16 (storage; arithmetic is fp32).  skip may be NULL.  y may alias x.
+ * Backward needs only the saved OUTPUT y: g = relu ? (y > 0 ? gy : 0) : gy; gx = g*scale[c]; gskip = g.
+ * gx or gskip may be NULL (not wanted); gskip may alias gy. */
+int ocpg_bn_act_fwd(const void* x, const float* scale, const float* shift, const void* skip, void* y,
+                    long long n_outer, int C, long long inner, int relu, int dtype, void* stream);
+int ocpg_bn_act_bwd(const void* gy, const void* y, const float* scale, void* gx, void* gskip,
+                    long long n_outer, int C, long long inner, int relu, int dtype, void* stream);
+
 /* library / build identification: returns e.g. "ocpg_hip gfx950 r1" */
 const char* ocpg_hip_version(void);
 

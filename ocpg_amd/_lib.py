@@ -22,6 +22,8 @@ SIGNATURES = {
     "ocpg_msda_fwd_f64": [_vp, _i64p, _i64p, _vp, _vp] + [_int] * 7 + [_vp, _vp],
     "ocpg_msda_bwd_f32": [_vp, _i64p, _i64p, _vp, _vp, _vp] + [_int] * 7 + [_vp, _vp, _vp, _vp, _vp],
     "ocpg_msda_bwd_f64": [_vp, _i64p, _i64p, _vp, _vp, _vp] + [_int] * 7 + [_vp, _vp, _vp, _vp],
+    "ocpg_bn_act_fwd": [_vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _int, ctypes.c_longlong, _int, _int, _vp],
+    "ocpg_bn_act_bwd": [_vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _int, ctypes.c_longlong, _int, _int, _vp],
 }
 
 

@@ -39,6 +39,10 @@ class SetCriterion(nn.Module):
         self.mask_out_stride_low = 2
         self.iter = 0
         self._warmup_iters = 100000
+        # optional device-resident copy of `iter` (0-dim float tensor) for callers that replay a captured HIP graph: a
+        # Python counter would be frozen into the graph; the caller advances it by 4 (calls per forward) per replay
+        self.iter_device = None
+        self._calls = 0
 
     # -- helpers ------------------------------------------------------------------------------------------
     @staticmethod
@@ -98,7 +102,11 @@ class SetCriterion(nn.Module):
         boxes = box_ops.box_cxcywh_to_xyxy(torch.cat([t["boxes"] for t in targets], dim=0))
         region = generate_box_region_mask(boxes, (im_h, im_w), sizes).view(-1, nf, im_h, im_w)
         region_low, region = sub(region, sl), sub(region, s)
-        warm = min(float(self.iter) / float(self._warmup_iters), 1.0)
+        if self.iter_device is None:
+            warm = min(float(self.iter) / float(self._warmup_iters), 1.0)
+        else:   # graph-replay mode: the call counter lives on the device; `_calls` = position of this call inside forward
+            self._calls += 1
+            warm = torch.clamp((self.iter_device + self._calls) / float(self._warmup_iters), max=1.0)
         weak_full, weak_low = sub(weak, s) * region, sub(weak, sl) * region_low
 
         loss_mask, _ = masked_ce_loss(src_masks, sub(heat, s), weak_full, region, num_boxes)
@@ -125,14 +133,22 @@ class SetCriterion(nn.Module):
         assert loss in table, f"do you really want to compute {loss} loss?"
         return table[loss](outputs, targets, indices, num_boxes, **kwargs)
 
-    def forward(self, outputs, targets):
-        indices = outputs["main_matcher_index"]
-        aux_indices = outputs["aux_matcher_index"]
-        device = outputs["pred_masks_low"].device
+    @staticmethod
+    def global_num_boxes(targets, device):
+        """Valid target frames averaged over ranks, clamped to >= 1 (criterion.py:224-231) -- a 0-dim device tensor; one
+        all-reduce, no .item().  Exposed so a caller that replays a captured HIP graph can run the collective outside it."""
         num_boxes = torch.stack([t["valid"] for t in targets]).sum().to(device=device, dtype=torch.float).reshape(1)
         if is_dist_avail_and_initialized():
             torch.distributed.all_reduce(num_boxes)
-        num_boxes = torch.clamp(num_boxes / get_world_size(), min=1)[0]
+        return torch.clamp(num_boxes / get_world_size(), min=1)[0]
+
+    def forward(self, outputs, targets):
+        self._calls = 0
+        indices = outputs["main_matcher_index"]
+        aux_indices = outputs["aux_matcher_index"]
+        num_boxes = outputs.get("num_boxes")       # optional: precomputed by the caller (see global_num_boxes)
+        if num_boxes is None:
+            num_boxes = self.global_num_boxes(targets, outputs["pred_masks_low"].device)
 
         losses, maps = {}, (None, None, None)
         for loss in self.losses:

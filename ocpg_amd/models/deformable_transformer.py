@@ -189,6 +189,20 @@ class DeformableTransformer(nn.Module):
         nn.init.zeros_(self.reference_points.bias)
         nn.init.normal_(self.level_embed)
 
+    def _level_geometry(self, shapes_host, dev):
+        """Device copies of (spatial_shapes, level_start_index) with their host twins attached, cached per geometry:
+        no host->device copy (and so nothing un-capturable by a HIP graph) happens after the first step."""
+        cache = self.__dict__.setdefault("_geom_cache", {})
+        key = (shapes_host, str(dev))
+        if key not in cache:
+            host = torch.tensor(shapes_host, dtype=torch.long)
+            starts_host = torch.cat((host.new_zeros(1), host.prod(1).cumsum(0)[:-1]))
+            spatial_shapes, level_start_index = host.to(dev), starts_host.to(dev)
+            spatial_shapes._ocpg_host = host
+            level_start_index._ocpg_host = starts_host
+            cache[key] = (spatial_shapes, level_start_index)
+        return cache[key]
+
     @staticmethod
     def get_valid_ratio(mask):
         _, h, w = mask.shape
@@ -204,12 +218,7 @@ class DeformableTransformer(nn.Module):
         src = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
         mask = torch.cat([m.flatten(1) for m in masks], 1)
         pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[l].view(1, 1, -1) for l, p in enumerate(pos_embeds)], 1)
-        host = torch.tensor(shapes_host, dtype=torch.long)
-        starts_host = torch.cat((host.new_zeros(1), host.prod(1).cumsum(0)[:-1]))
-        spatial_shapes = host.to(dev, non_blocking=True)
-        level_start_index = starts_host.to(dev, non_blocking=True)
-        spatial_shapes._ocpg_host = host
-        level_start_index._ocpg_host = starts_host
+        spatial_shapes, level_start_index = self._level_geometry(tuple(shapes_host), dev)
         valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
 
         memory = self.encoder(src, spatial_shapes, level_start_index, valid_ratios, pos, mask)

@@ -33,6 +33,8 @@ def _pairwise_giou_1(boxes, tgt):
 
 
 def _assert_well_formed(xyxy, what):
+    if xyxy.is_cuda and torch.cuda.is_current_stream_capturing():
+        return      # device-side asserts are kept out of captured graphs; the eager warm-up steps have checked already
     ok = (xyxy[..., 2:] >= xyxy[..., :2]).all()
     if xyxy.is_cuda:
         torch._assert_async(ok, f"error boxes: {what}")

@@ -3,7 +3,7 @@
 Follows the reference's models/modules.py:9-61: a 3x3 *valid* "laplace" conv -> global average -> FC -> sigmoid
 gives one coefficient per sample; the 2-D spectrum of the map is attenuated by (1 - coef * gaussian) where the
 Gaussian (sigma 7) is centred at (h//2, w//2) of the UNSHIFTED spectrum and, once created at the first level, is
-bilinearly resized for every later call; two 1x1 convs act on [real || imag]; inverse FFT; residual.  Always fp32.
+bilinearly resized for every later call; two 1x1 convs act on [real || imag]; inverse FFT; residual.
 """
 import torch
 import torch.nn.functional as F
@@ -28,17 +28,18 @@ class LFMResizeAdaptive(nn.Module):
         return torch.exp(-((ys - cy) ** 2 + (xs - cx) ** 2) / (2 * sigma ** 2))[None, None]
 
     def forward(self, x, gauss_map=None):
-        with torch.autocast(device_type=x.device.type, enabled=False):
-            b, c, h, w = x.shape
-            x = x.float()
-            # mean over positions commutes with the conv's bias/linear part, but keep the reference's op order
-            coef = self.fc(self.laplace(x).mean(dim=(2, 3))).view(b, 1, 1, 1)
-            if gauss_map is None:
-                high = self.make_gaussian(h // 2, w // 2, h, w, self.sigma, x.device)
-            else:
-                high = F.interpolate(gauss_map, size=(h, w), mode="bilinear", align_corners=False)
-            spec = torch.fft.fft2(x) * (1 - coef * high)
-            y = self.conv2(F.relu(self.conv1(torch.cat([spec.real, spec.imag], dim=1)))).float()
-            yr, yi = torch.chunk(y, 2, dim=1)
-            y = torch.fft.ifft2(torch.complex(yr, yi), s=(h, w)).real.float()
-            return x + y, high
+        # Precision follows the reference exactly: the input and the FFTs are fp32 (`x.float()`, modules.py:35), while the
+        # three convs / two FCs are ordinary autocast ops (fp16 in the reference's --amp runs, bf16 here) whose outputs
+        # are cast back with `.float()` (modules.py:56).  Without autocast everything is fp32.
+        b, c, h, w = x.shape
+        x = x.float()
+        coef = self.fc(self.laplace(x).mean(dim=(2, 3))).view(b, 1, 1, 1)
+        if gauss_map is None:
+            high = self.make_gaussian(h // 2, w // 2, h, w, self.sigma, x.device)
+        else:
+            high = F.interpolate(gauss_map, size=(h, w), mode="bilinear", align_corners=False)
+        spec = torch.fft.fft2(x) * (1 - coef.float() * high)
+        y = self.conv2(F.relu(self.conv1(torch.cat([spec.real, spec.imag], dim=1)))).float()
+        yr, yi = torch.chunk(y, 2, dim=1)
+        y = torch.fft.ifft2(torch.complex(yr, yi), s=(h, w)).real.float()
+        return x + y, high
