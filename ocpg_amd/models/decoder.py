@@ -30,7 +30,7 @@ class MSO(nn.Module):
         return self.out_conv(pred_masks)
 
 
-def _mso_forward_multi(self, pred_masks_list, image_features):
+def _mso_forward_multi(self, pred_masks_list, image_features, stacked=False):
     """Refine several mask sets (one per decoder layer) that share the SAME backbone features.
 
     conv(cat[relu(m), relu(f)]) = conv_m(relu(m)) + conv_f(relu(f)): the feature halves of conv1_1div8 / conv1_1div4
@@ -52,7 +52,8 @@ def _mso_forward_multi(self, pred_masks_list, image_features):
     shared4 = F.conv2d(F.relu(f4.to(dt)), w4[:, c:], self.conv1_1div4.bias, padding=1)
     y = F.conv2d(F.relu(pm), w4[:, :c], None, padding=1) + shared4.repeat(n, 1, 1, 1)
     pm = pm + self.conv2_1div4(F.relu(y))
-    return list(self.out_conv(pm).chunk(n, 0))
+    out = self.out_conv(pm)
+    return out if stacked else list(out.chunk(n, 0))
 
 
 MSO.forward_multi = _mso_forward_multi

@@ -53,54 +53,68 @@ class HungarianMatcher(nn.Module):
         self.mask_out_stride = 2
 
     @torch.no_grad()
+    def cost_matrix_stacked(self, logits, boxes, masks, targets):
+        """Matching cost of every query against the clip's single target for Lr decoder layers at once.
+        logits [Lr,B,T,q,K], boxes [Lr,B,T,q,4], masks [Lr,B,T,q,h,w] -> [Lr,B,q]."""
+        with torch.autocast(device_type=masks.device.type, enabled=False):
+            logits, boxes, masks = logits.float(), boxes.float(), masks.float()
+            lr, bs, nf, nq, h, w = masks.shape
+            gt, _ = nested_tensor_from_tensor_list([t["masks"] for t in targets], size_divisibility=32, split=False).decompose()
+            gt = gt.to(masks)
+            s = self.mask_out_stride
+            im_h, im_w = gt.shape[-2:]
+            gt = gt[:, :, s // 2::s, s // 2::s]
+            assert gt.size(2) * s == im_h and gt.size(3) * s == im_w
+
+            valid = torch.stack([t["valid"] for t in targets]).to(logits.dtype)                  # [B, T]
+            prob = logits.sigmoid()                                                              # [Lr, B, T, q, K]
+            alpha, gamma = 0.25, 2.0
+            neg = (1 - alpha) * (prob ** gamma) * (-(1 - prob + 1e-8).log())
+            pos = alpha * ((1 - prob) ** gamma) * (-(prob + 1e-8).log())
+            if self.num_classes == 1:
+                cls = (pos - neg)[..., 0]                                                         # [Lr, B, T, q]
+            else:
+                ids = torch.stack([t["labels"] for t in targets])                                # [B, T]
+                cls = torch.gather(pos - neg, 4, ids[None, :, :, None, None].expand(lr, -1, -1, nq, 1))[..., 0]
+            cost_class = (cls * valid[None, :, :, None]).sum(2) / valid.sum(1)[None, :, None]    # mean over valid frames
+
+            tb = torch.stack([t["boxes"] for t in targets]).to(boxes.dtype)                      # [B, T, 4]
+            cost_bbox = (boxes - tb[None, :, :, None, :]).abs().sum(-1).mean(2)                  # [Lr, B, q]
+            pb, tbx = box_cxcywh_to_xyxy(boxes), box_cxcywh_to_xyxy(tb)
+            _assert_well_formed(pb, "predictions")
+            _assert_well_formed(tbx, "targets")
+            cost_giou = -_pairwise_giou_1(pb, tbx[None, :, :, None, :]).mean(2)
+
+            x = masks.transpose(2, 3).flatten(3)                                                 # [Lr, B, q, T*h*w]
+            g = gt.flatten(1)[None, :, None, :]                                                  # [1, B, 1, T*h*w]
+            p = x.sigmoid()
+            ce = F.binary_cross_entropy_with_logits(x, g.expand_as(x), reduction="none")
+            p_t = p * g + (1 - p) * (1 - g)
+            focal = (alpha * g + (1 - alpha) * (1 - g)) * ce * ((1 - p_t) ** gamma)
+            cost_mask = focal.mean(3)
+            cost_dice = -((2 * (p * g).sum(3) + 1) / (p.sum(-1) + g.sum(-1) + 1))
+            return (self.cost_class * cost_class + self.cost_bbox * cost_bbox + self.cost_giou * cost_giou
+                    + self.cost_mask * cost_mask + self.cost_dice * cost_dice)
+
+    @torch.no_grad()
     def cost_matrix(self, outputs, targets):
         """[B, q] matching cost of every query against the clip's single target."""
-        logits, boxes, masks = outputs["pred_logits"], outputs["pred_boxes"], outputs["pred_masks"]
-        bs, nf, nq, h, w = masks.shape
-        gt, _ = nested_tensor_from_tensor_list([t["masks"] for t in targets], size_divisibility=32, split=False).decompose()
-        gt = gt.to(masks)
-        s = self.mask_out_stride
-        im_h, im_w = gt.shape[-2:]
-        gt = gt[:, :, s // 2::s, s // 2::s]
-        assert gt.size(2) * s == im_h and gt.size(3) * s == im_w
+        return self.cost_matrix_stacked(outputs["pred_logits"][None], outputs["pred_boxes"][None], outputs["pred_masks"][None], targets)[0]
 
-        valid = torch.stack([t["valid"] for t in targets]).to(logits.dtype)                  # [B, T]
-        prob = logits.sigmoid()                                                              # [B, T, q, K]
-        alpha, gamma = 0.25, 2.0
-        neg = (1 - alpha) * (prob ** gamma) * (-(1 - prob + 1e-8).log())
-        pos = alpha * ((1 - prob) ** gamma) * (-(prob + 1e-8).log())
-        if self.num_classes == 1:
-            cls = (pos - neg)[..., 0]                                                         # [B, T, q]
-        else:
-            ids = torch.stack([t["labels"] for t in targets])                                # [B, T]
-            cls = torch.gather(pos - neg, 3, ids[:, :, None, None].expand(-1, -1, nq, 1))[..., 0]
-        cost_class = (cls * valid[..., None]).sum(1) / valid.sum(1, keepdim=True)            # mean over valid frames
+    @torch.no_grad()
+    def match_stacked(self, logits, boxes, masks, targets):
+        """-> int64 [Lr, B]: argmin query per clip and layer (one sync-free tensor program for all decoder layers)."""
+        return self.cost_matrix_stacked(logits, boxes, masks, targets).argmin(dim=2)
 
-        tb = torch.stack([t["boxes"] for t in targets]).to(boxes.dtype)                      # [B, T, 4]
-        cost_bbox = (boxes - tb[:, :, None, :]).abs().sum(-1).mean(1)                        # [B, q]
-        pb, tbx = box_cxcywh_to_xyxy(boxes), box_cxcywh_to_xyxy(tb)
-        _assert_well_formed(pb, "predictions")
-        _assert_well_formed(tbx, "targets")
-        cost_giou = -_pairwise_giou_1(pb, tbx[:, :, None, :]).mean(1)
-
-        x = masks.transpose(1, 2).flatten(2)                                                 # [B, q, T*h*w]
-        g = gt.flatten(1)[:, None, :].expand(-1, nq, -1)
-        p = x.sigmoid()
-        ce = F.binary_cross_entropy_with_logits(x, g, reduction="none")
-        p_t = p * g + (1 - p) * (1 - g)
-        focal = (alpha * g + (1 - alpha) * (1 - g)) * ce * ((1 - p_t) ** gamma)
-        cost_mask = focal.mean(2)
-        cost_dice = -((2 * (p * g).sum(2) + 1) / (p.sum(-1) + g.sum(-1) + 1))
-
-        return (self.cost_class * cost_class + self.cost_bbox * cost_bbox + self.cost_giou * cost_giou
-                + self.cost_mask * cost_mask + self.cost_dice * cost_dice)
+    @staticmethod
+    def as_indices(src):
+        """[B] int64 -> the reference's list of (src_idx, tgt_idx) pairs (tgt is always 0: one object per clip)."""
+        zero = torch.zeros(1, dtype=torch.int64, device=src.device)
+        return [(src[i:i + 1], zero) for i in range(src.shape[0])]
 
     @torch.no_grad()
     def forward(self, outputs, targets):
-        C = self.cost_matrix(outputs, targets)
-        src = C.argmin(dim=1)                                                                # int64 [B]
-        zero = torch.zeros(1, dtype=torch.int64, device=src.device)
-        return [(src[i:i + 1], zero) for i in range(src.shape[0])]
+        return self.as_indices(self.cost_matrix(outputs, targets).argmin(dim=1))
 
 
 def build_matcher(args):

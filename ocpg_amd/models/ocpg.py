@@ -270,16 +270,18 @@ class OCPG(nn.Module):
             seg_masks_shuffled.append(F.pixel_shuffle(m.flatten(0, 1), 4).squeeze(1).view(b, t, self.num_queries, 4 * tar[0], 4 * tar[1]))
 
         if self.training:
+            # in-forward matching (ocpg.py:352-366), all decoder layers in ONE tensor program
+            shuffled = torch.stack(seg_masks_shuffled)                                # [l, b, t, q, 4h, 4w]
             with torch.no_grad():
+                if self.aux_loss:
+                    src_all = self.matcher.match_stacked(outputs_class, outputs_coord, shuffled, targets)      # [l, b]
+                else:
+                    src_all = self.matcher.match_stacked(outputs_class[-1:], outputs_coord[-1:], shuffled[-1:], targets)
                 out["pred_masks"] = seg_masks_shuffled[-1]
-                indices = self.matcher(out, targets)
-                out["main_matcher_index"] = indices
-                select = _get_src_permutation_idx(indices)
+                out["main_matcher_index"] = self.matcher.as_indices(src_all[-1])
                 if self.aux_loss:
                     out["aux_outputs"] = self._set_aux_loss(outputs_class, outputs_coord, seg_masks_shuffled)
-                    aux_indices = [self.matcher(a, targets) for a in out["aux_outputs"]]
-                    out["aux_matcher_index"] = aux_indices
-                    aux_select = [_get_src_permutation_idx(x) for x in aux_indices]
+                    out["aux_matcher_index"] = [self.matcher.as_indices(src_all[i]) for i in range(nl - 1)]
             if self.aux_loss:
                 ls_feat = F.interpolate(self.ls_feat_viz(memory_fusion), scale_factor=4, mode="bilinear", align_corners=True)
                 ls_feat = ls_feat.unflatten(0, (b, t))                              # [b, t, 8, 4h, 4w]
@@ -288,19 +290,24 @@ class OCPG(nn.Module):
                 img = F.interpolate(samples.tensors, ls_feat.shape[-2:], mode="bilinear", align_corners=True).unflatten(0, (b, t))
                 ls_features = torch.cat([img, ls_feat, sim.unsqueeze(2)], dim=2)    # [b, t, 12, 4h, 4w]  (same for every query)
 
-                selects = aux_select + [select]
-                picked = []
-                for m, (bi, qi) in zip(seg_masks, selects):
-                    m = m.view(b, t, self.num_queries, 16, tar[0], tar[1])
-                    picked.append(m[bi, :, qi].flatten(0, 1))                       # [(b t), 16, h, w]
-                refined = self.mask_refine.forward_multi(picked, features[:2])
-                refined = [F.interpolate(x, scale_factor=4).squeeze(1).unflatten(0, (b, t)) for x in refined]
+                # the matched query of every layer: one gather over [l, b, t, q, ...]
+                seg = torch.stack(seg_masks).view(nl, b, t, self.num_queries, 16, tar[0], tar[1])
+                gi = src_all[:, :, None, None, None, None, None].expand(nl, b, t, 1, 16, tar[0], tar[1])
+                picked = torch.gather(seg, 3, gi)[:, :, :, 0].flatten(1, 2)         # [l, (b t), 16, h, w]
+                refined = self.mask_refine.forward_multi(list(picked.unbind(0)), features[:2], stacked=True)   # [l*(b t), 1, 2h, 2w]
+                refined = F.interpolate(refined, scale_factor=4).squeeze(1)
+                refined = refined.view(nl, b, t, *refined.shape[-2:])
+                gl = src_all[:, :, None, None, None, None].expand(nl, b, t, 1, 4 * tar[0], 4 * tar[1])
+                low = torch.gather(shuffled, 3, gl)[:, :, :, 0]                     # [l, b, t, 4h, 4w]
                 out["pred_masks"] = refined[-1]
                 out["ls_features"] = ls_features
                 out["frames"] = img
-                low = [x.transpose(1, 2)[sel] for x, sel in zip(seg_masks_shuffled, selects)]      # [b, t, 4h, 4w]
                 out["pred_masks_low"] = low[-1]
                 out["aux_outputs"] = self._set_aux_loss_comprehensive(outputs_class, outputs_coord, refined, low, ls_features, img)
+                # layer-stacked views for the criterion, in ITS call order (main, aux 0, aux 1, ...): no re-stacking copies
+                order = [nl - 1] + list(range(nl - 1))
+                out["_stacked"] = {"pred_logits": outputs_class[order], "pred_boxes": outputs_coord[order],
+                                   "pred_masks": refined[order], "pred_masks_low": low[order]}
         elif self.args.dataset_file not in ("a2d", "jhmdb") and "refcoco" not in self.args.dataset_file:
             # YTVOS / DAVIS: keep the clip's best query (mean sigmoid score over frames), refine only that one
             m = seg_masks[-1].view(b, t, self.num_queries, 16, tar[0], tar[1])
