@@ -86,8 +86,16 @@ __global__ __launch_bounds__(256) void msda_fwd_fast(const float* __restrict__ v
   const int NS = L * P;
   const int MD = M * D;
   const int r = tid / G, j = tid % G;
+#ifndef MSDA_ROW_MAJOR
+  // XCD-aware mapping: blocks are dealt round-robin over the 8 XCDs, so block % M picks the HEAD; with M == 8 every
+  // XCD then gathers only its own head's 128-B slices of `value` (1/8 of the map) through its private 4-MiB L2.
+  const long long qrow = (long long)(blockIdx.x / M) * ROWS + r;          // flat (b, q)
+  const long long row = qrow * M + (blockIdx.x % M);
+  const bool live = qrow * M < rows;
+#else
   const long long row = (long long)blockIdx.x * ROWS + r;
   const bool live = row < rows;
+#endif
   if (live) {
     const float* lrow = loc + row * NS * 2;
     const float* arow = attn + row * NS;
@@ -196,8 +204,16 @@ __global__ __launch_bounds__(256) void msda_bwd_fast(const float* __restrict__ v
   const int NS = L * P;
   const int MD = M * D;
   const int r = tid / G, j = tid % G;
+#ifndef MSDA_ROW_MAJOR
+  // XCD-aware mapping: blocks are dealt round-robin over the 8 XCDs, so block % M picks the HEAD; with M == 8 every
+  // XCD then gathers only its own head's 128-B slices of `value` (1/8 of the map) through its private 4-MiB L2.
+  const long long qrow = (long long)(blockIdx.x / M) * ROWS + r;          // flat (b, q)
+  const long long row = qrow * M + (blockIdx.x % M);
+  const bool live = qrow * M < rows;
+#else
   const long long row = (long long)blockIdx.x * ROWS + r;
   const bool live = row < rows;
+#endif
   if (live) {
     const float* lrow = loc + row * NS * 2;
     const float* arow = attn + row * NS;
@@ -356,10 +372,17 @@ __global__ __launch_bounds__(256) void msda_bwd_tiled(const float* __restrict__ 
   }
   // decode (b, m, tile): all uniform
   int bid = blockIdx.x;
+#ifndef MSDA_ROW_MAJOR
+  const int m = bid % M;          // head fastest: block % 8 == XCD (round-robin dispatch) -> one head per XCD L2
+  bid /= M;
+  const int tile = bid % geo.ntiles;
+  const int b = bid / geo.ntiles;
+#else
   const int tile = bid % geo.ntiles;
   bid /= geo.ntiles;
   const int m = bid % M;
   const int b = bid / M;
+#endif
   int lq = 0;
   while (lq + 1 < L && tile >= geo.tile_base[lq + 1]) ++lq;
   const int t_in = tile - geo.tile_base[lq];
@@ -692,7 +715,11 @@ int ocpg_msda_fwd_f32(const float* value, const int64_t* shapes, const int64_t* 
   const size_t rec_bytes = (size_t)L * P * sizeof(SampleRec);
   if (G && L <= kMaxLevels && (256 / G) * rec_bytes <= 48 * 1024 && (long long)S * M * D < (1LL << 31)) {
     const int rpb = 256 / G;
+#ifndef MSDA_ROW_MAJOR
+    const unsigned grid = (unsigned)((((long long)N * Lq + rpb - 1) / rpb) * M);
+#else
     const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
+#endif
     const size_t lds = rpb * rec_bytes;
     FAST_DISPATCH(G, msda_fwd_fast, value, shapes, level_start, loc, attn, S, M, L, Lq, P, rows, out)
   } else {
@@ -734,16 +761,23 @@ int ocpg_msda_bwd_f32(const float* value, const int64_t* shapes, const int64_t* 
       const unsigned grid = (unsigned)((long long)N * M * geo.ntiles);
       const size_t lds = tiled_lds;
 #define TILED_LAUNCH(G_, NB_) msda_bwd_tiled<G_, NB_><<<grid, 256, lds, st>>>(value, shapes, level_start, loc, attn, grad_out, S, M, P, geo, grad_value, grad_loc, grad_attn)
-      const bool b4 = (P % 4) == 0;
+#ifndef MSDA_NB
+#define MSDA_NB 2
+#endif
+      const bool b4 = (P % MSDA_NB) == 0;
       switch (G) {
-        case 4: if (b4) TILED_LAUNCH(4, 4); else TILED_LAUNCH(4, 1); break;
-        case 8: if (b4) TILED_LAUNCH(8, 4); else TILED_LAUNCH(8, 1); break;
-        default: if (b4) TILED_LAUNCH(16, 4); else TILED_LAUNCH(16, 1); break;
+        case 4: if (b4) TILED_LAUNCH(4, MSDA_NB); else TILED_LAUNCH(4, 1); break;
+        case 8: if (b4) TILED_LAUNCH(8, MSDA_NB); else TILED_LAUNCH(8, 1); break;
+        default: if (b4) TILED_LAUNCH(16, MSDA_NB); else TILED_LAUNCH(16, 1); break;
       }
 #undef TILED_LAUNCH
       return launch_status();
     }
+#ifndef MSDA_ROW_MAJOR
+    const unsigned grid = (unsigned)((((long long)N * Lq + rpb - 1) / rpb) * M);
+#else
     const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
+#endif
     const size_t lds = rpb * rec_bytes;
     FAST_DISPATCH(G, msda_bwd_fast, value, shapes, level_start, loc, attn, grad_out, S, M, L, Lq, P, rows, grad_value, grad_loc,
                   grad_attn)
