@@ -226,7 +226,7 @@ def build_tiny(seed=1, **over):
     B = 2
     model, crit, _ = ref_import.build_reference_model(args, tiny_text(B))
     full = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-    model.load_state_dict(synth.synth_state_dict(synth.shapes_of(model), seed=seed))
+    model.load_state_dict(synth.synth_state_dict(synth.shapes_of(model), seed=seed), strict=False)   # integer buffers keep their own values
     # bernoulli streams cannot be matched across implementations: every dropout (incl. the FeatureResizers'
     # hard-coded 0.1, ocpg.py:85-94) is disabled on both sides for the parity fixtures
     for m in model.modules():
@@ -356,9 +356,104 @@ def gen_e2e_tiny():
     save("e2e_tiny", meta, **arrays)
 
 
+
+SWIN_TINY = dict(patch_size=(1, 4, 4), embed_dim=24, depths=[2, 2, 2, 2], num_heads=[3, 3, 6, 6], window_size=(8, 7, 7),
+                 mlp_ratio=2.0, qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.0,
+                 patch_norm=True, use_checkpoint=False)
+
+
+def gen_swin3d():
+    ref_import.install()
+    import models.video_swin_transformer as vs
+    arrays, meta = {}, {"swin_tiny": SWIN_TINY}
+    # (a) WindowAttention3D, small window, with and without a shift mask
+    wa = vs.WindowAttention3D(24, (2, 3, 3), 3, qkv_bias=True)
+    shp = synth.shapes_of(wa)
+    wa.load_state_dict(synth.synth_state_dict(shp, seed=6), strict=False)
+    meta["wa_shapes"] = shp
+    x = synth.rand("wa_x", (8, 18, 24)).requires_grad_(True)
+    mask = vs.compute_mask(2, 6, 6, (2, 3, 3), (0, 1, 1), "cpu")
+    arrays["wa_mask"] = mask
+    for tag, m in (("nomask", None), ("mask", mask)):
+        y = wa(x, m)
+        g = torch.autograd.grad((y * synth.rand("wa_go", y.shape)).sum(), [x] + list(wa.parameters()))
+        arrays[f"wa_{tag}_y"], arrays[f"wa_{tag}_gx"] = y, g[0]
+        for (k, _), gg in zip(wa.named_parameters(), g[1:]):
+            arrays[f"wa_{tag}_gp_{k}"] = gg
+    # (a') the real clamped case: module built for (8,7,7), tokens of a (5,7,7) window -> index table sliced [:245,:245]
+    wb = vs.WindowAttention3D(24, (8, 7, 7), 3, qkv_bias=True)
+    shpb = synth.shapes_of(wb)
+    wb.load_state_dict(synth.synth_state_dict(shpb, seed=7), strict=False)
+    meta["wb_shapes"] = shpb
+    xb = synth.rand("wb_x", (2, 245, 24))
+    arrays["wb_y"] = wb(xb, None)
+    # (b) shift masks
+    arrays["mask_5_14_21"] = vs.compute_mask(5, 14, 21, (5, 7, 7), (0, 3, 3), "cpu")
+    arrays["mask_8_7_14"] = vs.compute_mask(8, 7, 14, (4, 7, 7), (2, 0, 3), "cpu")
+    # (c) a shifted block on a map that needs padding; temporal axis clamped
+    blk = vs.SwinTransformerBlock3D(24, 3, window_size=(8, 7, 7), shift_size=(4, 3, 3), mlp_ratio=2.0)
+    shpc = synth.shapes_of(blk)
+    blk.load_state_dict(synth.synth_state_dict(shpc, seed=8), strict=False)
+    meta["blk_shapes"] = shpc
+    xc = synth.rand("blk_x", (2, 5, 10, 13, 24)).requires_grad_(True)
+    am = vs.compute_mask(5, 14, 14, (5, 7, 7), (0, 3, 3), "cpu")
+    yc = blk(xc, am)
+    gc = torch.autograd.grad((yc * synth.rand("blk_go", yc.shape)).sum(), [xc] + list(blk.parameters()))
+    arrays["blk_y"], arrays["blk_gx"] = yc, gc[0]
+    meta["blk_grad_norms"] = {k: float(g.norm()) for (k, _), g in zip(blk.named_parameters(), gc[1:])}
+    # (d) patch merging with odd sizes
+    pm = vs.PatchMerging(24)
+    shpd = synth.shapes_of(pm)
+    pm.load_state_dict(synth.synth_state_dict(shpd, seed=9))
+    meta["pm_shapes"] = shpd
+    arrays["pm_y"] = pm(synth.rand("pm_x", (2, 3, 5, 7, 24)))
+    # (e) the whole backbone wrapper, tiny configuration, 5 frames of 64 x 96
+    bb = vs.VideoSwinTransformerBackbone(False, None, True, (0, 1, 2, 3), **SWIN_TINY)
+    shpe = synth.shapes_of(bb)
+    bb.load_state_dict(synth.synth_state_dict(shpe, seed=10), strict=False)
+    meta["bb_shapes"] = shpe
+    xe = synth.rand("bb_x", (5, 3, 64, 96)).requires_grad_(True)
+    out = bb(xe, 5)
+    loss = 0
+    for k, v in out.items():
+        arrays[f"bb_out{k}"] = v
+        loss = loss + (v * synth.rand(f"bb_go{k}", v.shape)).sum()
+    ge = torch.autograd.grad(loss, [xe] + list(bb.parameters()), allow_unused=True)
+    arrays["bb_gx"] = ge[0]
+    meta["bb_grad_norms"] = {k: (float(g.norm()) if g is not None else None) for (k, _), g in zip(bb.named_parameters(), ge[1:])}
+    save("swin3d", meta, **arrays)
+
+
+def gen_e2e_swin():
+    """OCPG end to end with the Video-Swin backbone (tiny Swin configuration), train mode."""
+    ref_import.install()
+    import models.video_swin_transformer as vs
+    vs.configs["video_swin_t_p4w7"] = dict(SWIN_TINY)
+    arrays, meta = {}, {}
+    args, cfg, model, crit, full = build_tiny(backbone="video_swin_t_p4w7", backbone_pretrained=None, use_checkpoint=False, output_levels=4)
+    B, T, H, W = 2, 2, 192, 224
+    sizes = [(192, 224), (160, 200)]
+    out, targets = run_e2e(model, crit, B, T, H, W, sizes)
+    losses, *_ = crit(out, targets)
+    wd = crit.weight_dict
+    total = sum(losses[k] * wd[k] for k in losses if k in wd)
+    total.backward()
+    for k in ("pred_logits", "pred_boxes", "pred_masks", "pred_masks_low"):
+        arrays[f"pad_{k}"] = out[k]
+    arrays["pad_main_idx"] = torch.stack([i[0] for i in out["main_matcher_index"]])
+    arrays["pad_aux_idx"] = torch.stack([torch.stack([i[0] for i in a]) for a in out["aux_matcher_index"]])
+    arrays["pad_total"] = total
+    meta["pad_losses"] = {k: float(v) for k, v in losses.items()}
+    meta["pad_grad_norms"] = {k: (float(p.grad.norm()) if p.grad is not None else None) for k, p in model.named_parameters()}
+    meta["pad_sizes"] = sizes
+    meta.update(cfg=cfg, swin_cfg=SWIN_TINY, seed=1, B=B, T=T, H=H, W=W, state_shapes=full, float_shapes=synth.shapes_of(model))
+    save("e2e_swin", meta, **arrays)
+
+
 GENS = {"msda_testpy": gen_msda_testpy, "msda_cases": gen_msda_cases, "msda_module": gen_msda_module,
         "transformer": gen_transformer, "lfm": gen_lfm, "fusion": gen_fusion, "dynmask_mso": gen_dynmask_mso,
-        "matcher_crit": gen_matcher_crit, "e2e_tiny": gen_e2e_tiny}
+        "matcher_crit": gen_matcher_crit, "e2e_tiny": gen_e2e_tiny,
+        "swin3d": gen_swin3d, "e2e_swin": gen_e2e_swin}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GENS)

@@ -42,3 +42,20 @@ def test_train_step_matches_reference(golden, dev, tag):
 @pytest.mark.parametrize("tag", ["nopad", "pad"])
 def test_eval_tail_matches_reference(golden, dev, tag):
     model_checks.run_eval(golden("e2e_tiny"), tag, dev, rtol=1e-3, atol=1e-4)
+
+
+# ---- Video-Swin backbone (BASELINE configs #4 / #5) ----------------------------------------------------------
+def test_swin_window_attention_and_masks(golden, dev):
+    import swin_checks as sc
+    sc.check_window_attention(golden("swin3d"), dev, rtol=5e-4, atol=5e-5)
+
+
+def test_swin_block_and_backbone(golden, dev):
+    import swin_checks as sc
+    sc.check_block_and_merging(golden("swin3d"), dev, rtol=5e-4, atol=1e-4)
+    sc.check_backbone(golden("swin3d"), dev, rtol=1e-3, atol=2e-4)
+
+
+def test_e2e_with_video_swin(golden, dev):
+    import swin_checks as sc
+    sc.check_e2e_swin(golden("e2e_swin"), dev, rtol=1e-3, atol=1e-4)
