@@ -28,27 +28,38 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
-T_FRAMES, HEIGHT, WIDTH = 5, 384, 640
+T_FRAMES, HEIGHT, WIDTH = 5, 384, 640        # BASELINE config #2/#3/#4 clip; --frames/--height/--width override (config #5: 8x480x854)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def model_args(device, backbone="resnet101", amp=True):
+def model_args(device, backbone="resnet101", amp=True, roberta=False):
     from cases import default_args
     return default_args(device=str(device), backbone=backbone, num_frames=T_FRAMES, num_queries=5, num_feature_levels=4,
                         enc_layers=4, dec_layers=4, hidden_dim=256, dim_feedforward=2048, dropout=0.1, amp=amp,
-                        text_encoder_lazy=True)
+                        text_encoder_lazy=not roberta)
 
 
-def synthetic_batch(n_clips, device, seed):
-    """SURVEY.md section 8d recipe: randn clips (already 'normalised'), random text features, one box per frame."""
+def synthetic_batch(n_clips, device, seed, roberta=False):
+    """SURVEY.md section 8d recipe: randn clips (already 'normalised'), random text features (or, for config #5, captions
+    that go through the random-init RoBERTa-base), one box per frame.  Widths that are not a multiple of 32 are padded
+    like collate_fn does (util/misc.py:302), with the padding mask set."""
     from synth import synthetic_targets
     from ocpg_amd.models.text_encoder.text_encoder import PrecomputedText
     from ocpg_amd.util.misc import NestedTensor
     g = torch.Generator(device="cpu").manual_seed(seed)
-    x = torch.randn(n_clips, T_FRAMES, 3, HEIGHT, WIDTH, generator=g).to(device)
-    mask = torch.zeros(n_clips, T_FRAMES, HEIGHT, WIDTH, dtype=torch.bool, device=device)
-    text = PrecomputedText(torch.randn(n_clips, 9, 768, generator=g).to(device), torch.randn(n_clips, 768, generator=g).to(device),
-                           torch.zeros(n_clips, 9, dtype=torch.bool, device=device))
+    hp, wp = (HEIGHT + 31) // 32 * 32, (WIDTH + 31) // 32 * 32
+    x = torch.zeros(n_clips, T_FRAMES, 3, hp, wp)
+    x[..., :HEIGHT, :WIDTH] = torch.randn(n_clips, T_FRAMES, 3, HEIGHT, WIDTH, generator=g)
+    x = x.to(device)
+    mask = torch.ones(n_clips, T_FRAMES, hp, wp, dtype=torch.bool)
+    mask[..., :HEIGHT, :WIDTH] = False
+    mask = mask.to(device)
+    if roberta:
+        words = ["the", "person", "on", "left", "riding", "a", "red", "bike", "near", "tree", "small", "dog"]
+        text = [" ".join(words[(i + j) % len(words)] for j in range(10)) for i in range(n_clips)]
+    else:
+        text = PrecomputedText(torch.randn(n_clips, 9, 768, generator=g).to(device), torch.randn(n_clips, 768, generator=g).to(device),
+                               torch.zeros(n_clips, 9, dtype=torch.bool, device=device))
     targets = synthetic_targets(n_clips, T_FRAMES, HEIGHT, WIDTH, device)
     return (lambda: NestedTensor(x.clone(), mask.clone())), text, targets
 
@@ -172,7 +183,7 @@ def time_msda_kernels(n_frames, device, iters=20):
     """Live HIP-event timing of the MSDeformAttn kernels at the encoder / decoder shapes of this run, on the launch
     stream (used when the step itself is a graph replay, where per-kernel events cannot be interleaved)."""
     from ocpg_amd.models.ops.functions import ms_deform_attn_func as f
-    shapes_l = [(HEIGHT // 8 >> i, WIDTH // 8 >> i) for i in range(4)]
+    shapes_l = [((HEIGHT + 31) // 32 * 32 // 8 >> i, (WIDTH + 31) // 32 * 32 // 8 >> i) for i in range(4)]
     shapes = torch.tensor(shapes_l, dtype=torch.long)
     ls = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
     S = int(shapes.prod(1).sum())
@@ -226,6 +237,11 @@ def main():
     ap.add_argument("--clips-per-gpu", type=int, default=2)
     ap.add_argument("--backbone", default="resnet101")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--frames", type=int, default=T_FRAMES)
+    ap.add_argument("--height", type=int, default=HEIGHT)
+    ap.add_argument("--width", type=int, default=WIDTH)
+    ap.add_argument("--text", default="features", choices=["features", "roberta"],
+                    help="features: random [B,9,768] text features (configs #1-#4); roberta: captions through RoBERTa-base (config #5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--graph", action="store_true",
@@ -234,6 +250,8 @@ def main():
                          "alive (memory-reuse hazard inside the captured graph, see DESIGN.md section 5); the self-check below "
                          "falls back to eager when that happens.")
     a = ap.parse_args()
+    global T_FRAMES, HEIGHT, WIDTH
+    T_FRAMES, HEIGHT, WIDTH = a.frames, a.height, a.width
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -252,14 +270,14 @@ def main():
 
     torch.manual_seed(42 + rank)
     torch.backends.cudnn.benchmark = True
-    args = model_args(device, a.backbone, amp=a.dtype != "fp32")
+    args = model_args(device, a.backbone, amp=a.dtype != "fp32", roberta=a.text == "roberta")
     model, criterion, _ = build_model(args)
     model.to(device).to(memory_format=torch.channels_last)
     criterion.to(device)
     model.train(), criterion.train()
     optimizer = make_optimizer(model, args)
     amp_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}[a.dtype]
-    make_samples, text, targets = synthetic_batch(a.clips_per_gpu, device, seed=42 + rank)
+    make_samples, text, targets = synthetic_batch(a.clips_per_gpu, device, seed=42 + rank, roberta=a.text == "roberta")
     step, mode = None, "eager"
     if a.graph:
         try:
@@ -315,20 +333,23 @@ def main():
 
     clips = a.steps * a.clips_per_gpu * world
     line = {
-        "metric": "clips/sec fwd+bwd (5x384x640, R101)", "value": clips / dt, "unit": "clips/s", "n_gpus": world,
+        "metric": "clips/sec fwd+bwd (5x384x640, R101)" if (a.backbone, a.frames, a.height, a.width) == ("resnet101", 5, 384, 640)
+        else f"clips/sec fwd+bwd ({a.frames}x{a.height}x{a.width}, {a.backbone})", "value": clips / dt, "unit": "clips/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": f"{a.backbone} + 4-scale deformable transformer (4 enc + 4 dec), {T_FRAMES}x{HEIGHT}x{WIDTH} clips, "
                                f"5 queries, {a.clips_per_gpu} clips/GPU/step, step = fwd + criterion + bwd + clip + AdamW",
                    "global_batch": a.clips_per_gpu * world, "parallelism": f"dp{world}", "weights": "random init",
-                   "text": "random features [B,9,768] (RoBERTa bypassed, BASELINE configs #1-#4)", "launch": mode},
+                   "text": "random features [B,9,768] (RoBERTa bypassed, BASELINE configs #1-#4)" if a.text == "features"
+                           else "10-word captions through a random-init RoBERTa-base (frozen)", "launch": mode},
         "final_loss": float(loss.detach()),
     }
     if rank == 0:
         key = "bwd_enc"
         if key in kt and kt[key]["n"]:
             n_frames = a.clips_per_gpu * T_FRAMES
-            S, M, D, LP = 5100, 8, 32, 16
+            hp, wp = (HEIGHT + 31) // 32 * 32, (WIDTH + 31) // 32 * 32
+            S, M, D, LP = sum((hp // 8 >> i) * (wp // 8 >> i) for i in range(4)), 8, 32, 16
             fwd_b = 4 * n_frames * (S * M * D + S * M * D + 3 * S * M * LP)
             bwd_b = fwd_b + 4 * n_frames * (S * M * D) + 4 * n_frames * (S * M * D + 3 * S * M * LP)
             us = kt[key]["ms"] / kt[key]["n"] * 1e3
@@ -337,7 +358,7 @@ def main():
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                                 "launch_us": us, "algorithmic_bytes": bwd_b, "launches_timed": kt[key]["n"]}
             line["kernel_us"] = {k: v["ms"] / max(v["n"], 1) * 1e3 for k, v in kt.items()}
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.backbone.startswith("resnet"):
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:
