@@ -32,14 +32,33 @@ def _pairwise_giou_1(boxes, tgt):
     return iou - ((hull - union) + 1e-6) / (hull + 1e-6)
 
 
+_BOX_ERRORS = {}      # device -> 0-dim int32 counter of malformed-box events (GPU path: recorded, never trapped)
+
+
 def _assert_well_formed(xyxy, what):
-    if xyxy.is_cuda and torch.cuda.is_current_stream_capturing():
-        return      # device-side asserts are kept out of captured graphs; the eager warm-up steps have checked already
+    """The reference asserts x1 >= x0 and y1 >= y0 on the host (util/box_ops.py:75-76), which costs a device sync per
+    call.  On the GPU the violation is COUNTED in a device-side flag instead (no sync, no device trap -- a trapping
+    assert would take the process down with a GPU core dump); `raise_if_malformed_boxes()` turns it into the
+    reference's AssertionError at the caller's next natural sync point.  On the CPU it asserts immediately."""
     ok = (xyxy[..., 2:] >= xyxy[..., :2]).all()
     if xyxy.is_cuda:
-        torch._assert_async(ok, f"error boxes: {what}")
+        flag = _BOX_ERRORS.get(xyxy.device)
+        if flag is None:
+            if torch.cuda.is_current_stream_capturing():
+                return
+            flag = _BOX_ERRORS[xyxy.device] = torch.zeros((), dtype=torch.int32, device=xyxy.device)
+        flag += (~ok).to(torch.int32)
     else:
         assert ok, f"error boxes: {what}"
+
+
+def raise_if_malformed_boxes():
+    """Host-side check of the device flags (one sync).  Call it where the training loop already synchronises."""
+    for dev, flag in _BOX_ERRORS.items():
+        n = int(flag.item())
+        if n:
+            flag.zero_()
+            raise AssertionError(f"error boxes: {n} malformed (x1 < x0 or y1 < y0, or NaN) box set(s) seen on {dev}")
 
 
 class HungarianMatcher(nn.Module):
