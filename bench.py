@@ -372,8 +372,15 @@ def main():
             bwd_b = fwd_b + 4 * n_frames * (S * M * D) + 4 * n_frames * (S * M * D + 3 * S * M * LP)
             us = kt[key]["ms"] / kt[key]["n"] * 1e3
             ach = bwd_b / us / 1e3
+            traffic = None          # HBM bytes per launch from the committed rocprofv3 --pmc passes (same shape, same kernel)
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_msda_pmc.json")))
+                if pmc["n_frames"] == n_frames and (HEIGHT, WIDTH) == (384, 640):
+                    traffic = pmc["msda_bwd_tiled"]["hbm_bytes_per_launch"]
+            except (OSError, KeyError, ValueError):
+                pass
             line["roofline"] = {"bound": "hbm", "kernel": "msda_bwd (encoder shape, N=%d frames)" % n_frames, "achieved": ach,
-                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                                 "launch_us": us, "algorithmic_bytes": bwd_b, "launches_timed": kt[key]["n"]}
             line["kernel_us"] = {k: v["ms"] / max(v["n"], 1) * 1e3 for k, v in kt.items()}
         if world == 1 and not a.no_cpu_baseline and a.backbone.startswith("resnet"):

@@ -9,7 +9,7 @@ shapes_l = [(48, 80), (24, 40), (12, 20), (6, 10)]
 shapes = torch.tensor(shapes_l, dtype=torch.long)
 ls = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
 S = int(shapes.prod(1).sum())
-N, M, D, L, P = 5, 8, 32, 4, 4
+N, M, D, L, P = int(os.environ.get("MSDA_FRAMES", "5")), 8, 32, 4, 4
 
 
 def inputs(Lq, mode):
