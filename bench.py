@@ -229,13 +229,13 @@ def time_msda_kernels(n_frames, device, iters=20):
     return out
 
 
-def cpu_baseline(sample_frames=T_FRAMES):
+def cpu_baseline(state_shapes):
     """Time the CPU oracle (a restatement of the reference path) on ONE clip: forward + criterion + backward."""
     try:
         from oracle import ocpg_ref
     except ImportError:
         return None
-    return ocpg_ref.timed_baseline(model_args("cpu", amp=False), sample_frames, HEIGHT, WIDTH)
+    return ocpg_ref.timed_baseline(model_args("cpu", amp=False), state_shapes, T_FRAMES, HEIGHT, WIDTH)
 
 
 def main():
@@ -384,7 +384,7 @@ def main():
                                 "launch_us": us, "algorithmic_bytes": bwd_b, "launches_timed": kt[key]["n"]}
             line["kernel_us"] = {k: v["ms"] / max(v["n"], 1) * 1e3 for k, v in kt.items()}
         if world == 1 and not a.no_cpu_baseline and a.backbone.startswith("resnet"):
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = cpu_baseline({k: tuple(v.shape) for k, v in model.state_dict().items() if v.dtype.is_floating_point})
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

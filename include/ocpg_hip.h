@@ -73,6 +73,22 @@ int ocpg_bn_act_fwd(const void* x, const float* scale, const float* shift, const
 int ocpg_bn_act_bwd(const void* gy, const void* y, const float* scale, void* gx, void* gskip,
                     long long n_outer, int C, long long inner, int relu, int dtype, void* stream);
 
+/* Fused 3-D (shifted-)window attention of Video-Swin -- replaces WindowAttention3D.forward's score / bias / mask /
+ * softmax / PV chain (models/video_swin_transformer.py:138-169) and the shift-mask tensor of compute_mask (:316-329).
+ *   qkv    [BW, N, 3, H, head_dim]   output of the qkv Linear (BW = batch * windows), head_dim must be 32
+ *   bias   [H, N, N]  relative-position bias (query i, key j);  biasT [H, N, N] the same transposed (key j, query i)
+ *   region [NW, N] int32 cyclic-shift region id of every window slot, or NULL (no shift); window = bw % NW;
+ *          a (query, key) pair in different regions gets -100 added, exactly like the reference's mask
+ *   out    [BW, N, H*head_dim];  lse [BW, H, N] fp32 log-sum-exp of every row (saved for the backward)
+ * dtype: 0 float32, 1 bfloat16, 2 float16 (storage of qkv/out/dout/dqkv; arithmetic and bias/lse are fp32).
+ * Backward: dqkv [BW, N, 3, H, head_dim] fully overwritten; Dbuf [BW, H, N] fp32 scratch;
+ * dbiasT [H, N, N] fp32 is ACCUMULATED into (caller zeroes it; may be NULL when the bias needs no gradient). */
+int ocpg_win_attn_fwd(const void* qkv, const float* biasT, const int* region, float scale, int BW, int NW, int N, int H,
+                      int head_dim, void* out, float* lse, int dtype, void* stream);
+int ocpg_win_attn_bwd(const void* qkv, const float* bias, const float* biasT, const int* region, float scale, int BW, int NW,
+                      int N, int H, int head_dim, const void* out, const void* dout, const float* lse, void* dqkv, float* Dbuf,
+                      float* dbiasT, int dtype, void* stream);
+
 /* library / build identification: returns e.g. "ocpg_hip gfx950 r1" */
 const char* ocpg_hip_version(void);
 

@@ -24,6 +24,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..util.misc import NestedTensor
+from .ops.functions.win_attn_func import window_attention
 from .position_encoding import build_position_encoding
 
 
@@ -123,12 +124,20 @@ class WindowAttention3D(nn.Module):
         idx = self.relative_position_index[:n, :n].reshape(-1)
         return self.relative_position_bias_table[idx].view(n, n, -1).permute(2, 0, 1)
 
-    def forward(self, x, mask=None):
-        """x [num_windows*B, N, C]; mask [num_windows, N, N] additive (0 / -100) or None."""
+    def forward(self, x, mask=None, region=None):
+        """x [num_windows*B, N, C]; mask [num_windows, N, N] additive (0 / -100) or None; region [num_windows, N] int32 =
+        the same shift mask as region ids (what the fused HIP kernel consumes instead of the N x N tensor)."""
         bw, n, c = x.shape
         h = self.num_heads
-        qkv = self.qkv(x).view(bw, n, 3, h, c // h).permute(2, 0, 3, 1, 4)
-        bias = self.relative_position_bias(n).unsqueeze(0)                               # [1, h, N, N]
+        qkv = self.qkv(x)
+        bias = self.relative_position_bias(n)                                            # [h, N, N]
+        if x.is_cuda and c // h == 32 and (self.attn_drop.p == 0.0 or not self.training) and (mask is None or region is not None):
+            nw = region.shape[0] if region is not None else 1
+            out = window_attention(qkv.view(bw, n, 3, h, c // h), bias, region, self.scale, nw)      # csrc/win_attn.hip
+            return self.proj_drop(self.proj(out))
+        # generic path (CPU unit tests of the host logic, head_dim != 32, attention dropout): torch's fused SDPA
+        qkv = qkv.view(bw, n, 3, h, c // h).permute(2, 0, 3, 1, 4)
+        bias = bias.unsqueeze(0)
         if mask is not None:
             nw = mask.shape[0]
             bias = (bias + mask.unsqueeze(1)).unsqueeze(0).expand(bw // nw, nw, h, n, n).reshape(bw, h, n, n)
@@ -159,21 +168,23 @@ class SwinTransformerBlock3D(nn.Module):
         key = (D, H, W, ws, ss, str(device))
         if key not in cache:
             src_w, inv, region_w, _ = _window_plan(D, H, W, ws, ss)
-            mask = None
+            mask = region = None
             if any(s > 0 for s in ss):
                 r = torch.from_numpy(region_w)
-                diff = r[:, None, :] - r[:, :, None]
-                mask = torch.zeros(diff.shape, dtype=torch.float32).masked_fill(diff != 0, -100.0).to(device)
-            cache[key] = (torch.from_numpy(src_w.reshape(-1)).to(device), torch.from_numpy(inv).to(device), mask, src_w.shape)
+                region = r.to(torch.int32).contiguous().to(device)
+                if device.type != "cuda":        # the N x N additive mask only exists for the generic (SDPA) path
+                    diff = r[:, None, :] - r[:, :, None]
+                    mask = torch.zeros(diff.shape, dtype=torch.float32).masked_fill(diff != 0, -100.0).to(device)
+            cache[key] = (torch.from_numpy(src_w.reshape(-1)).to(device), torch.from_numpy(inv).to(device), mask, region, src_w.shape)
         return cache[key]
 
     def forward_part1(self, x, mask_matrix=None):
         B, D, H, W, C = x.shape
-        gather_in, gather_out, mask, (nw, n) = self._plan(D, H, W, x.device)
+        gather_in, gather_out, mask, region, (nw, n) = self._plan(D, H, W, x.device)
         x = self.norm1(x).view(B, D * H * W, C)
         x = torch.cat([x, x.new_zeros(B, 1, C)], dim=1)                                   # the zero row read by padded slots
         windows = x.index_select(1, gather_in).view(B * nw, n, C)                         # pad + roll + partition: one gather
-        out = self.attn(windows, mask=mask).view(B, nw * n, C)
+        out = self.attn(windows, mask=mask, region=region).view(B, nw * n, C)
         return out.index_select(1, gather_out).view(B, D, H, W, C)                        # reverse + un-roll + crop: one gather
 
     def forward_part2(self, x):

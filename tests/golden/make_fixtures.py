@@ -357,7 +357,8 @@ def gen_e2e_tiny():
 
 
 
-SWIN_TINY = dict(patch_size=(1, 4, 4), embed_dim=24, depths=[2, 2, 2, 2], num_heads=[3, 3, 6, 6], window_size=(8, 7, 7),
+# head_dim is 32 at every stage (like Swin-T/S/B), so the product's fused HIP window-attention kernel is what runs on the GPU
+SWIN_TINY = dict(patch_size=(1, 4, 4), embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], window_size=(8, 7, 7),
                  mlp_ratio=2.0, qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.0,
                  patch_norm=True, use_checkpoint=False)
 
@@ -387,6 +388,21 @@ def gen_swin3d():
     meta["wb_shapes"] = shpb
     xb = synth.rand("wb_x", (2, 245, 24))
     arrays["wb_y"] = wb(xb, None)
+    # (a'') head_dim 32 (the fused-kernel shape): dim 96 / 3 heads, clamped (5,7,7) window, real shift mask, with grads
+    wc = vs.WindowAttention3D(96, (8, 7, 7), 3, qkv_bias=True)
+    shpw = synth.shapes_of(wc)
+    wc.load_state_dict(synth.synth_state_dict(shpw, seed=11), strict=False)
+    meta["wc_shapes"] = shpw
+    maskc = vs.compute_mask(5, 14, 14, (5, 7, 7), (0, 3, 3), "cpu")          # 4 windows
+    xw = synth.rand("wc_x", (8, 245, 96)).requires_grad_(True)
+    for tag, m in (("nomask", None), ("mask", maskc)):
+        y = wc(xw, m)
+        g = torch.autograd.grad((y * synth.rand("wc_go", y.shape)).sum(), [xw] + list(wc.parameters()))
+        arrays[f"wc_{tag}_y"], arrays[f"wc_{tag}_gx"] = y, g[0]
+        for (k, _), gg in zip(wc.named_parameters(), g[1:]):
+            if "bias_table" in k:
+                arrays[f"wc_{tag}_gtable"] = gg
+            meta.setdefault(f"wc_{tag}_grad_norms", {})[k] = float(gg.norm())
     # (b) shift masks
     arrays["mask_5_14_21"] = vs.compute_mask(5, 14, 21, (5, 7, 7), (0, 3, 3), "cpu")
     arrays["mask_8_7_14"] = vs.compute_mask(8, 7, 14, (4, 7, 7), (2, 0, 3), "cpu")

@@ -31,6 +31,24 @@ def check_window_attention(g, dev, rtol=1e-4, atol=1e-5):
     _load(wb, g.meta["wb_shapes"], 7)
     wb.to(dev)
     close(wb(synth.rand("wb_x", (2, 245, 24)).to(dev), None), g["wb_y"], rtol, atol, "clamped-window attention")
+    # head_dim 32: on the GPU this is the fused HIP kernel (csrc/win_attn.hip), on the CPU the generic path
+    wc = vs.WindowAttention3D(96, (8, 7, 7), 3, qkv_bias=True)
+    _load(wc, g.meta["wc_shapes"], 11)
+    wc.to(dev)
+    blk = vs.SwinTransformerBlock3D(96, 3, window_size=(8, 7, 7), shift_size=(4, 3, 3))
+    regionc = blk._plan(5, 14, 14, dev)[3]                                     # region ids of the 4 shifted windows
+    maskc = vs.compute_mask(5, 14, 14, (5, 7, 7), (0, 3, 3), dev) if dev.type != "cuda" else None
+    xw = synth.rand("wc_x", (8, 245, 96)).to(dev).requires_grad_(True)
+    for tag, use_mask in (("nomask", False), ("mask", True)):
+        y = wc(xw, maskc if use_mask else None, regionc if use_mask else None)
+        close(y, g[f"wc_{tag}_y"], rtol, atol, f"wc {tag} y")
+        grads = torch.autograd.grad((y * synth.rand("wc_go", y.shape).to(dev)).sum(), [xw] + list(wc.parameters()))
+        close(grads[0], g[f"wc_{tag}_gx"], rtol * 10, atol * 10, f"wc {tag} gx")
+        for (k, _), gg in zip(wc.named_parameters(), grads[1:]):
+            ref = g.meta[f"wc_{tag}_grad_norms"][k]
+            assert abs(gg.norm().item() - ref) <= 2e-3 * abs(ref) + 1e-5, (tag, k, gg.norm().item(), ref)
+            if "bias_table" in k:
+                close(gg, g[f"wc_{tag}_gtable"], rtol * 10, atol * 50, f"wc {tag} bias-table grad")
     # integer buffers must equal the reference's by construction
     close(vs.compute_mask(5, 14, 21, (5, 7, 7), (0, 3, 3), dev), g["mask_5_14_21"], 0, 0, "mask 5x14x21")
     close(vs.compute_mask(8, 7, 14, (4, 7, 7), (2, 0, 3), dev), g["mask_8_7_14"], 0, 0, "mask 8x7x14")
