@@ -28,6 +28,10 @@ from .ops.functions.win_attn_func import window_attention
 from .position_encoding import build_position_encoding
 
 
+import os
+_GENERIC_ATTENTION = os.environ.get("OCPG_GENERIC_WINDOW_ATTENTION") == "1"      # A/B switch: torch SDPA instead of csrc/win_attn.hip
+
+
 class DropPath(nn.Module):
     """Stochastic depth per sample (timm.models.layers.DropPath semantics)."""
 
@@ -131,13 +135,17 @@ class WindowAttention3D(nn.Module):
         h = self.num_heads
         qkv = self.qkv(x)
         bias = self.relative_position_bias(n)                                            # [h, N, N]
-        if x.is_cuda and c // h == 32 and (self.attn_drop.p == 0.0 or not self.training) and (mask is None or region is not None):
+        if (x.is_cuda and c // h == 32 and (self.attn_drop.p == 0.0 or not self.training) and (mask is None or region is not None)
+                and not _GENERIC_ATTENTION):
             nw = region.shape[0] if region is not None else 1
             out = window_attention(qkv.view(bw, n, 3, h, c // h), bias, region, self.scale, nw)      # csrc/win_attn.hip
             return self.proj_drop(self.proj(out))
         # generic path (CPU unit tests of the host logic, head_dim != 32, attention dropout): torch's fused SDPA
         qkv = qkv.view(bw, n, 3, h, c // h).permute(2, 0, 3, 1, 4)
         bias = bias.unsqueeze(0)
+        if mask is None and region is not None:          # the additive N x N form of the same shift mask
+            r = region.long()
+            mask = torch.zeros((r.shape[0], n, n), dtype=torch.float32, device=x.device).masked_fill(r[:, None, :] != r[:, :, None], -100.0)
         if mask is not None:
             nw = mask.shape[0]
             bias = (bias + mask.unsqueeze(1)).unsqueeze(0).expand(bw // nw, nw, h, n, n).reshape(bw, h, n, n)
@@ -260,7 +268,14 @@ class PatchEmbed3D(nn.Module):
         pd, ph, pw = self.patch_size
         if W % pw or H % ph or D % pd:
             x = F.pad(x, (0, (pw - W % pw) % pw, 0, (ph - H % ph) % ph, 0, (pd - D % pd) % pd))
-        x = self.proj(x)
+        if pd == 1:
+            # temporal patch size 1 (every Video-Swin config of the reference): the Conv3d is a per-frame 2-D conv.
+            # Same weights ([C, 3, 1, ph, pw], checkpoint-compatible), but MIOpen's 2-D path instead of its 3-D solvers.
+            b, c, d, h, w = x.shape
+            y = F.conv2d(x.transpose(1, 2).reshape(b * d, c, h, w), self.proj.weight.squeeze(2), self.proj.bias, stride=(ph, pw))
+            x = y.view(b, d, self.embed_dim, y.shape[-2], y.shape[-1]).transpose(1, 2)
+        else:
+            x = self.proj(x)
         if self.norm is not None:
             x = self.norm(x.permute(0, 2, 3, 4, 1)).permute(0, 4, 1, 2, 3)
         return x
