@@ -23,6 +23,8 @@ import time
 
 import torch
 import torch.distributed as dist
+import torch.utils._python_dispatch
+import torch.utils._pytree
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -119,6 +121,22 @@ class EagerStep:
         return loss
 
 
+class _KeepEveryTensor(torch.utils._python_dispatch.TorchDispatchMode):
+    """Holds a reference to every tensor any op produces while active (forward and the autograd thread alike), so that NO
+    block of the graph's private pool is freed and re-used inside the capture.  Re-use inside a captured graph is what
+    goes wrong on replay on ROCm 7.2; with 288 GB of HBM the extra residency (every intermediate of
+    one forward+backward, a few tens of GB) is affordable."""
+
+    def __init__(self):
+        super().__init__()
+        self.keep = []
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        out = func(*args, **(kwargs or {}))
+        torch.utils._pytree.tree_map_only(torch.Tensor, self.keep.append, out)
+        return out
+
+
 class GraphStep:
     """Same step with forward + criterion + backward captured once into a HIP graph and replayed (launch-bound inner
     loop: ~9 500 kernels per step).  Outside the graph, per step: copy the batch into the static input buffers, the
@@ -149,9 +167,11 @@ class GraphStep:
         # the THIRD replay return NaN gradients (tools/dbg_graph2.py, KEEP=... bisect); with them alive replays match
         # eager.  self.check() compares a replay against an eager step before the timed region.
         self.static = {}
-        with torch.cuda.graph(self.graph):
+        keeper = _KeepEveryTensor()
+        with torch.cuda.graph(self.graph), keeper:
             self.loss = forward_backward(model, criterion, NestedTensor(self.x.clone(), self.mask.clone()), text, targets, amp_dtype,
                                          self.num_boxes, keep=self.static)
+        self._alive = keeper.keep
         self.grads = [p.grad for p in self.params]
         assert all(g is not None for g in self.grads), "a trainable parameter received no gradient"
         self.flat = None
@@ -292,6 +312,7 @@ def main():
     make_samples, text, targets = synthetic_batch(a.clips_per_gpu, device, seed=42 + rank, roberta=a.text == "roberta")
     step, mode = None, "eager"
     if a.graph:
+        snapshot = {k: v.clone() for k, v in model.state_dict().items()}
         try:
             torch.manual_seed(1234 + rank)
             model.zero_grad(set_to_none=True)
@@ -307,7 +328,15 @@ def main():
         except Exception as e:      # capture is an optimisation, never a requirement: report and run eagerly
             print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {str(e)[:200]}); running eagerly", file=sys.stderr, flush=True)
             torch.cuda.synchronize()
-            optimizer.zero_grad(set_to_none=True)
+            step = None
+            model.load_state_dict(snapshot)                      # the failed replays may have poisoned the weights
+            optimizer = make_optimizer(model, args)
+            criterion.iter_device, criterion.iter = None, 0
+            try:
+                from ocpg_amd.models.matcher import raise_if_malformed_boxes
+                raise_if_malformed_boxes()
+            except AssertionError:
+                pass
     if step is None:
         ddp_model = model
         if world > 1:

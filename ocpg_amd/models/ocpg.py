@@ -305,9 +305,10 @@ class OCPG(nn.Module):
                 out["pred_masks_low"] = low[-1]
                 out["aux_outputs"] = self._set_aux_loss_comprehensive(outputs_class, outputs_coord, refined, low, ls_features, img)
                 # layer-stacked views for the criterion, in ITS call order (main, aux 0, aux 1, ...): no re-stacking copies
-                order = [nl - 1] + list(range(nl - 1))
-                out["_stacked"] = {"pred_logits": outputs_class[order], "pred_boxes": outputs_coord[order],
-                                   "pred_masks": refined[order], "pred_masks_low": low[order]}
+                def main_first(x):      # (slices + cat: no host-built index tensor, so the step stays graph-capturable)
+                    return torch.cat([x[nl - 1:], x[:nl - 1]], dim=0)
+                out["_stacked"] = {"pred_logits": main_first(outputs_class), "pred_boxes": main_first(outputs_coord),
+                                   "pred_masks": main_first(refined), "pred_masks_low": main_first(low)}
         elif self.args.dataset_file not in ("a2d", "jhmdb") and "refcoco" not in self.args.dataset_file:
             # YTVOS / DAVIS: keep the clip's best query (mean sigmoid score over frames), refine only that one
             m = seg_masks[-1].view(b, t, self.num_queries, 16, tar[0], tar[1])
