@@ -5,6 +5,9 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import amp_cache
+from .amp_cache import lookup
+
 
 class MultiheadAttention(nn.Module):
     def __init__(self, embed_dim, num_heads, dropout=0.0):
@@ -13,7 +16,8 @@ class MultiheadAttention(nn.Module):
         self.embed_dim, self.num_heads, self.dropout = embed_dim, num_heads, dropout
         self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
         self.in_proj_bias = nn.Parameter(torch.zeros(3 * embed_dim))
-        self.out_proj = nn.Linear(embed_dim, embed_dim)
+        self.out_proj = amp_cache.Linear(embed_dim, embed_dim)
+        amp_cache.register(self, self.in_proj_weight, self.in_proj_bias)
         nn.init.xavier_uniform_(self.in_proj_weight)
         nn.init.zeros_(self.out_proj.bias)
 
@@ -22,7 +26,7 @@ class MultiheadAttention(nn.Module):
         Lq, B, C = query.shape
         Lk = key.shape[0]
         H, hd = self.num_heads, C // self.num_heads
-        w, b = self.in_proj_weight, self.in_proj_bias
+        w, b = lookup(self.in_proj_weight), lookup(self.in_proj_bias)
         q = F.linear(query, w[:C], b[:C]).view(Lq, B, H, hd).permute(1, 2, 0, 3)
         k = F.linear(key, w[C:2 * C], b[C:2 * C]).view(Lk, B, H, hd).permute(1, 2, 0, 3)
         v = F.linear(value, w[2 * C:], b[2 * C:]).view(Lk, B, H, hd).permute(1, 2, 0, 3)

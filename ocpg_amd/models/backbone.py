@@ -14,6 +14,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..util.misc import NestedTensor
+from . import amp_cache
 from .ops.functions.bn_act_func import frozen_bn_act
 from .position_encoding import build_position_encoding
 
@@ -64,15 +65,15 @@ class FrozenBatchNorm2d(nn.Module):
 class Bottleneck(nn.Module):
     def __init__(self, cin, width, stride, dilation, project):
         super().__init__()
-        self.conv1 = nn.Conv2d(cin, width, 1, bias=False)
+        self.conv1 = amp_cache.Conv2d(cin, width, 1, bias=False)
         self.bn1 = FrozenBatchNorm2d(width)
-        self.conv2 = nn.Conv2d(width, width, 3, stride=stride, padding=dilation, dilation=dilation, bias=False)
+        self.conv2 = amp_cache.Conv2d(width, width, 3, stride=stride, padding=dilation, dilation=dilation, bias=False)
         self.bn2 = FrozenBatchNorm2d(width)
-        self.conv3 = nn.Conv2d(width, width * 4, 1, bias=False)
+        self.conv3 = amp_cache.Conv2d(width, width * 4, 1, bias=False)
         self.bn3 = FrozenBatchNorm2d(width * 4)
         self.downsample = None
         if project:
-            self.downsample = nn.Sequential(nn.Conv2d(cin, width * 4, 1, stride=stride, bias=False),
+            self.downsample = nn.Sequential(amp_cache.Conv2d(cin, width * 4, 1, stride=stride, bias=False),
                                             FrozenBatchNorm2d(width * 4))
 
     def forward(self, x):
@@ -88,7 +89,7 @@ class ResNetBody(nn.Module):
     def __init__(self, name, dilation=False, return_interm_layers=True):
         super().__init__()
         depths = _STAGES[name]
-        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.conv1 = amp_cache.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
         self.bn1 = FrozenBatchNorm2d(64)
         cin, dil = 64, 1
         for i, (width, n) in enumerate(zip((64, 128, 256, 512), depths)):

@@ -7,16 +7,19 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import amp_cache
+from .amp_cache import lookup
+
 
 class MSO(nn.Module):
     def __init__(self, mask_dim=16, img_dim=(96, 192), out_dim=16):
         super().__init__()
         self.mask_dim, self.img_dim, self.out_dim = mask_dim, list(img_dim), out_dim
-        self.conv1_1div8 = nn.Conv2d(mask_dim + img_dim[1], mask_dim, kernel_size=3, padding=1)
-        self.conv2_1div8 = nn.Conv2d(mask_dim, mask_dim, kernel_size=3, padding=1)
-        self.conv1_1div4 = nn.Conv2d(mask_dim + img_dim[0], mask_dim, kernel_size=3, padding=1)
-        self.conv2_1div4 = nn.Conv2d(mask_dim, mask_dim, kernel_size=3, padding=1)
-        self.out_conv = nn.Conv2d(mask_dim, 1, kernel_size=3, padding=1)
+        self.conv1_1div8 = amp_cache.Conv2d(mask_dim + img_dim[1], mask_dim, kernel_size=3, padding=1)
+        self.conv2_1div8 = amp_cache.Conv2d(mask_dim, mask_dim, kernel_size=3, padding=1)
+        self.conv1_1div4 = amp_cache.Conv2d(mask_dim + img_dim[0], mask_dim, kernel_size=3, padding=1)
+        self.conv2_1div4 = amp_cache.Conv2d(mask_dim, mask_dim, kernel_size=3, padding=1)
+        self.out_conv = amp_cache.Conv2d(mask_dim, 1, kernel_size=3, padding=1)
 
     def forward(self, pred_masks, image_features):
         f4, f8 = (x.tensors for x in image_features)           # stride 4, stride 8
@@ -42,14 +45,14 @@ def _mso_forward_multi(self, pred_masks_list, image_features, stacked=False):
     pm = torch.cat(pred_masks_list, 0)
     dt = pm.dtype
     assert pm.shape[-1] == f8.shape[-1], "First size wrong."
-    w8 = self.conv1_1div8.weight
-    shared8 = F.conv2d(F.relu(f8.to(dt)), w8[:, c:], self.conv1_1div8.bias, padding=1)
+    w8 = lookup(self.conv1_1div8.weight)
+    shared8 = F.conv2d(F.relu(f8.to(dt)), w8[:, c:], lookup(self.conv1_1div8.bias), padding=1)
     y = F.conv2d(F.relu(pm), w8[:, :c], None, padding=1) + shared8.repeat(n, 1, 1, 1)
     pm = pm + self.conv2_1div8(F.relu(y))
     pm = F.interpolate(pm, size=f4.shape[-2:], mode="bilinear", align_corners=False)
     assert pm.shape[-1] == f4.shape[-1], "Second size wrong."
-    w4 = self.conv1_1div4.weight
-    shared4 = F.conv2d(F.relu(f4.to(dt)), w4[:, c:], self.conv1_1div4.bias, padding=1)
+    w4 = lookup(self.conv1_1div4.weight)
+    shared4 = F.conv2d(F.relu(f4.to(dt)), w4[:, c:], lookup(self.conv1_1div4.bias), padding=1)
     y = F.conv2d(F.relu(pm), w4[:, :c], None, padding=1) + shared4.repeat(n, 1, 1, 1)
     pm = pm + self.conv2_1div4(F.relu(y))
     out = self.out_conv(pm)

@@ -16,6 +16,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..util.misc import inverse_sigmoid
+from . import amp_cache
 from .attention import MultiheadAttention
 from .ops.modules import MSDeformAttn
 
@@ -40,10 +41,10 @@ class DeformableTransformerEncoderLayer(nn.Module):
         self.self_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
         self.dropout1 = nn.Dropout(dropout)
         self.norm1 = nn.LayerNorm(d_model)
-        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.linear1 = amp_cache.Linear(d_model, d_ffn)
         self.activation = _activation(activation)
         self.dropout2 = nn.Dropout(dropout)
-        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.linear2 = amp_cache.Linear(d_ffn, d_model)
         self.dropout3 = nn.Dropout(dropout)
         self.norm2 = nn.LayerNorm(d_model)
 
@@ -95,10 +96,10 @@ class DeformableTransformerDecoderLayer(nn.Module):
         self.self_attn = MultiheadAttention(d_model, n_heads, dropout=dropout)
         self.dropout2 = nn.Dropout(dropout)
         self.norm2 = nn.LayerNorm(d_model)
-        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.linear1 = amp_cache.Linear(d_model, d_ffn)
         self.activation = _activation(activation)
         self.dropout3 = nn.Dropout(dropout)
-        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.linear2 = amp_cache.Linear(d_ffn, d_model)
         self.dropout4 = nn.Dropout(dropout)
         self.norm3 = nn.LayerNorm(d_model)
 
@@ -175,7 +176,7 @@ class DeformableTransformer(nn.Module):
             DeformableTransformerDecoderLayer(d_model, dim_feedforward, dropout, activation, num_feature_levels, nhead, dec_n_points),
             num_decoder_layers, return_intermediate_dec)
         self.level_embed = nn.Parameter(torch.empty(num_feature_levels, d_model))
-        self.reference_points = nn.Linear(d_model, 2)
+        self.reference_points = amp_cache.Linear(d_model, 2)
         self._reset_parameters()
 
     def _reset_parameters(self):

@@ -9,17 +9,19 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import amp_cache
+
 
 class LFMResizeAdaptive(nn.Module):
     def __init__(self, num_channels, sigma):
         super().__init__()
-        self.conv1 = nn.Conv2d(2 * num_channels, 2 * num_channels, kernel_size=1)
-        self.conv2 = nn.Conv2d(2 * num_channels, 2 * num_channels, kernel_size=1)
+        self.conv1 = amp_cache.Conv2d(2 * num_channels, 2 * num_channels, kernel_size=1)
+        self.conv2 = amp_cache.Conv2d(2 * num_channels, 2 * num_channels, kernel_size=1)
         self.sigma = sigma
-        self.laplace = nn.Conv2d(num_channels, num_channels, kernel_size=3, padding=0)
+        self.laplace = amp_cache.Conv2d(num_channels, num_channels, kernel_size=3, padding=0)
         self.pool = nn.AdaptiveAvgPool2d(1)
-        self.fc = nn.Sequential(nn.Linear(num_channels, num_channels, bias=False), nn.ReLU(inplace=True),
-                                nn.Linear(num_channels, 1, bias=False), nn.Sigmoid())
+        self.fc = nn.Sequential(amp_cache.Linear(num_channels, num_channels, bias=False), nn.ReLU(inplace=True),
+                                amp_cache.Linear(num_channels, 1, bias=False), nn.Sigmoid())
 
     @staticmethod
     def make_gaussian(cy, cx, height, width, sigma=7, device="cpu"):

@@ -22,6 +22,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..util.misc import NestedTensor, inverse_sigmoid, nested_tensor_from_videos_list
+from . import amp_cache
 from .backbone import build_backbone
 from .criterion import SetCriterion
 from .decoder import MSO
@@ -46,7 +47,7 @@ class MLP(nn.Module):
         super().__init__()
         self.num_layers = num_layers
         dims = [input_dim] + [hidden_dim] * (num_layers - 1) + [output_dim]
-        self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+        self.layers = nn.ModuleList(amp_cache.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
 
     def forward(self, x):
         for i, layer in enumerate(self.layers):
@@ -99,10 +100,10 @@ class OCPG(nn.Module):
         self.aux_loss = aux_loss
         self.with_box_refine = with_box_refine
         self.num_classes = num_classes
-        self.class_embed = nn.Linear(hidden_dim, num_classes)
+        self.class_embed = amp_cache.Linear(hidden_dim, num_classes)
         self.bbox_embed = MLP(hidden_dim, hidden_dim, 4, 3)
-        self.ls_feat_viz = nn.Conv2d(hidden_dim, 8, 3, 1, 1)
-        self.ls_text_proj = nn.Linear(hidden_dim, 8)
+        self.ls_feat_viz = amp_cache.Conv2d(hidden_dim, 8, 3, 1, 1)
+        self.ls_text_proj = amp_cache.Linear(hidden_dim, 8)
         self.mask_dim = mask_dim
         self.controller_layers = controller_layers
         self.dynamic_mask_channels = dynamic_mask_channels
@@ -123,10 +124,10 @@ class OCPG(nn.Module):
         chans = backbone.num_channels[-3:]
         proj, fft, fft_post = [], [], []
         for cin in chans:
-            proj.append(nn.Sequential(nn.Conv2d(cin, hidden_dim, kernel_size=1), nn.GroupNorm(32, hidden_dim)))
+            proj.append(nn.Sequential(amp_cache.Conv2d(cin, hidden_dim, kernel_size=1), nn.GroupNorm(32, hidden_dim)))
         cin = chans[-1]
         for _ in range(num_feature_levels - len(chans)):
-            proj.append(nn.Sequential(nn.Conv2d(cin, hidden_dim, kernel_size=3, stride=2, padding=1), nn.GroupNorm(32, hidden_dim)))
+            proj.append(nn.Sequential(amp_cache.Conv2d(cin, hidden_dim, kernel_size=3, stride=2, padding=1), nn.GroupNorm(32, hidden_dim)))
             cin = hidden_dim
         for _ in range(len(proj)):
             fft.append(LFMResizeAdaptive(hidden_dim, 7))
@@ -198,6 +199,10 @@ class OCPG(nn.Module):
     def forward(self, samples, captions, targets):
         """samples: NestedTensor([B,T,3,H,W], mask [B,T,H,W]) or list of [T,3,H,W]; captions: list[str] (or
         PrecomputedText); targets: list[dict] (needs 'size'; training also needs the matcher/criterion keys)."""
+        with amp_cache.scope(self):        # one fused low-precision cast of all autocast-consumed parameters
+            return self._forward(samples, captions, targets)
+
+    def _forward(self, samples, captions, targets):
         if not isinstance(samples, NestedTensor):
             samples = nested_tensor_from_videos_list(samples, 1 if self.training else 16)
         features, visual_pos = self.backbone(samples)        # NB: folds samples to [(b t), ...] in place

@@ -17,6 +17,8 @@ from typing import NamedTuple
 import torch
 from torch import nn
 
+from .. import amp_cache
+
 
 class PrecomputedText(NamedTuple):
     """Stand-in for the encoder output: features [B,L,768], sentence [B,768], pad_mask [B,L] (True = padding)."""
@@ -31,7 +33,7 @@ class FeatureResizer(nn.Module):
     def __init__(self, input_feat_size, output_feat_size, dropout, do_ln=True):
         super().__init__()
         self.do_ln = do_ln
-        self.fc = nn.Linear(input_feat_size, output_feat_size, bias=True)
+        self.fc = amp_cache.Linear(input_feat_size, output_feat_size, bias=True)
         self.layer_norm = nn.LayerNorm(output_feat_size, eps=1e-12)
         self.dropout = nn.Dropout(dropout)
 

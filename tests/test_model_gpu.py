@@ -59,3 +59,35 @@ def test_swin_block_and_backbone(golden, dev):
 def test_e2e_with_video_swin(golden, dev):
     import swin_checks as sc
     sc.check_e2e_swin(golden("e2e_swin"), dev, rtol=1e-3, atol=1e-4)
+
+
+def test_fused_autocast_param_cast_equals_per_op_casts(golden, dev):
+    """amp_cache (one fused cast of all parameters per forward) must give exactly what autocast's own casts give."""
+    import cases
+    from ocpg_amd.models import amp_cache
+    from ocpg_amd.util.misc import NestedTensor
+    g = golden("e2e_tiny")
+    meta = g.meta
+    res = []
+    for enabled in (True, False):
+        amp_cache.ENABLED = enabled
+        try:
+            torch.manual_seed(0)
+            args, model, crit = model_checks.build_product(meta, dev)
+            B, T, H, W = meta["B"], meta["T"], meta["H"], meta["W"]
+            x, mask, targets = cases.e2e_inputs(B, T, H, W, meta["nopad_sizes"], dev)
+            model.train(), crit.train()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = model(NestedTensor(x, mask), model_checks.text_for(B, dev), targets)
+                losses, *_ = crit(out, targets)
+                total = sum(losses[k] * crit.weight_dict[k] for k in losses if k in crit.weight_dict)
+            total.backward()
+            gn = {k: p.grad.float().norm().item() for k, p in model.named_parameters() if p.grad is not None}
+            res.append((out["pred_masks"].detach().float().cpu(), total.item(), gn))
+        finally:
+            amp_cache.ENABLED = True
+    (m1, t1, g1), (m0, t0, g0) = res
+    assert torch.equal(m1, m0) and t1 == t0
+    assert set(g1) == set(g0)
+    bad = [(k, g1[k], g0[k]) for k in g1 if abs(g1[k] - g0[k]) > 2e-2 * abs(g0[k]) + 1e-6]
+    assert not bad, bad[:5]
