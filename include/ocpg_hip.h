@@ -89,6 +89,15 @@ int ocpg_win_attn_bwd(const void* qkv, const float* bias, const float* biasT, co
                       int N, int H, int head_dim, const void* out, const void* dout, const float* lse, void* dqkv, float* Dbuf,
                       float* dbiasT, int dtype, void* stream);
 
+/* Dynamic (per-query) mask head, forward -- replaces OCPG.dynamic_mask_with_coords + mask_heads_forward
+ * (models/ocpg.py:475-549) for the reference's fixed head shape (2 layers, 16 channels, relative coordinates on):
+ *   feats  [BT, C, H, W] fp32 mask features;  params [BT*Q, (C+2)*16 + 16*16 + 16 + 16] controller outputs in the
+ *   reference's order (parse_dynamic_params, ocpg.py:552-569: W0 [16,(C+2)] incl. the x,y coordinate columns, W1 [16,16],
+ *   b0, b1);  refpix [BT*Q, 2] reference point in INPUT pixels (ref_xy * (img_w, img_h));  stride = mask_feat_stride (8)
+ *   out    [BT*Q, 16, H, W];  pre1 [BT*Q, 16, H, W] = layer-1 pre-activation (kept for the backward; may be NULL). */
+int ocpg_dynmask_fwd_f32(const float* feats, const float* params, const float* refpix, int BT, int Q, int C, int H, int W,
+                         int stride, float* out, float* pre1, void* stream);
+
 /* library / build identification: returns e.g. "ocpg_hip gfx950 r1" */
 const char* ocpg_hip_version(void);
 

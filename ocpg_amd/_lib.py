@@ -24,6 +24,7 @@ SIGNATURES = {
     "ocpg_msda_bwd_f64": [_vp, _i64p, _i64p, _vp, _vp, _vp] + [_int] * 7 + [_vp, _vp, _vp, _vp],
     "ocpg_bn_act_fwd": [_vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _int, ctypes.c_longlong, _int, _int, _vp],
     "ocpg_bn_act_bwd": [_vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _int, ctypes.c_longlong, _int, _int, _vp],
+    "ocpg_dynmask_fwd_f32": [_vp, _vp, _vp] + [_int] * 6 + [_vp, _vp, _vp],
     "ocpg_win_attn_fwd": [_vp, _vp, _vp, ctypes.c_float] + [_int] * 5 + [_vp, _vp, _int, _vp],
     "ocpg_win_attn_bwd": [_vp, _vp, _vp, _vp, ctypes.c_float] + [_int] * 5 + [_vp] * 6 + [_int, _vp],
 }

@@ -29,6 +29,7 @@ from .decoder import MSO
 from .deformable_transformer import build_deforamble_transformer
 from .matcher import build_matcher
 from .modules import LFMResizeAdaptive
+from .ops.functions.dynmask_func import dynamic_mask
 from .position_encoding import PositionEmbeddingSine1D
 from .postprocessors import build_postprocessors
 from .resample import bicubic_resize
@@ -359,6 +360,13 @@ class OCPG(nn.Module):
             b, t, c, h, w = feats.shape
             nq = reference_points.shape[1] // t
             ch = self.dynamic_mask_channels
+            if feats.is_cuda and self.rel_coord and self.controller_layers == 2 and ch == 16:
+                # fused HIP forward (csrc/dynmask.hip): coordinates + both per-query 1x1 convs in one pass over the features
+                sizes = torch.stack([tg["size"] for tg in targets]).to(feats.device, torch.float32)         # [b, 2] (h, w)
+                refpix = reference_points.float() * torch.stack([sizes[:, 1], sizes[:, 0]], -1)[:, None, :]  # [b, t*q, 2]
+                out = dynamic_mask(feats.reshape(b * t, c, h, w), mask_head_params.float().reshape(b * t * nq, -1),
+                                   refpix.reshape(b * t * nq, 2), self.mask_feat_stride)
+                return out.view(b, t * nq, ch, h, w)
             params = mask_head_params.float().reshape(b, t, nq, -1)
             parts = torch.split_with_sizes(params, self.weight_nums + self.bias_nums, dim=-1)
             n_layers = len(self.weight_nums)
