@@ -62,15 +62,17 @@ def test_e2e_with_video_swin(golden, dev):
 
 
 def test_fused_autocast_param_cast_equals_per_op_casts(golden, dev):
-    """amp_cache (one fused cast of all parameters per forward) must give what autocast's own per-op casts give (same
-    casts, same kernels; run-to-run the bf16 GEMM/conv kernels differ in the last bf16 bit, hence the norm-relative bound)."""
+    """amp_cache (one fused cast of all parameters per forward) must give what autocast's own per-op casts give.  The
+    casts themselves are checked bit-exactly; the end-to-end bf16 step is not reproducible run to run on this stack
+    (library GEMM/conv kernels: ~2e-2 norm-relative on the tiny model's mask logits between two identical runs), so the
+    on-vs-off difference is bounded by the measured off-vs-off noise floor."""
     import cases
     from ocpg_amd.models import amp_cache
     from ocpg_amd.util.misc import NestedTensor
     g = golden("e2e_tiny")
     meta = g.meta
-    res = []
-    for enabled in (True, False):
+
+    def run(enabled):
         amp_cache.ENABLED = enabled
         try:
             torch.manual_seed(0)
@@ -83,12 +85,28 @@ def test_fused_autocast_param_cast_equals_per_op_casts(golden, dev):
                 losses, *_ = crit(out, targets)
                 total = sum(losses[k] * crit.weight_dict[k] for k in losses if k in crit.weight_dict)
             total.backward()
-            gn = {k: p.grad.float().norm().item() for k, p in model.named_parameters() if p.grad is not None}
-            res.append((out["pred_masks"].detach().float().cpu(), total.item(), gn))
+            gn = {k: p.grad.float().clone() for k, p in model.named_parameters() if p.grad is not None}
+            if enabled:     # the fused cast itself: every cached copy is the bf16 rounding of its parameter, bit for bit
+                with amp_cache.scope(model), torch.autocast("cuda", dtype=torch.bfloat16):
+                    for k, p in model.named_parameters():
+                        c = amp_cache.lookup(p)
+                        if c is not p:
+                            assert c.dtype == torch.bfloat16 and torch.equal(c, p.detach().to(torch.bfloat16)), k
+            return out["pred_masks"].detach().float().cpu(), total.item(), gn
         finally:
             amp_cache.ENABLED = True
-    (m1, t1, g1), (m0, t0, g0) = res
-    assert (m1 - m0).norm() <= 1e-2 * m0.norm() and abs(t1 - t0) <= 1e-2 * abs(t0)
+
+    (m0, t0, g0), (m0b, t0b, g0b), (m1, t1, g1) = run(False), run(False), run(True)
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-20))
+    floor_m, floor_t = rel(m0b, m0), abs(t0b - t0) / abs(t0)
+    assert rel(m1, m0) <= 3 * floor_m + 1e-3, (rel(m1, m0), floor_m)
+    assert abs(t1 - t0) <= 3 * floor_t * abs(t0) + 1e-2 * abs(t0), (t1, t0, t0b)
     assert set(g1) == set(g0)
-    bad = [(k, g1[k], g0[k]) for k in g1 if abs(g1[k] - g0[k]) > 5e-2 * abs(g0[k]) + 1e-5]
-    assert not bad, bad[:5]
+    # gradients: some (LFM gates, deep backbone convs) move by tens of percent between two IDENTICAL bf16 runs, so compare the
+    # on-vs-off change of every parameter's gradient with its own off-vs-off change
+    d_on = {k: rel(g1[k], g0[k]) for k in g0 if g0[k].norm() > 0}
+    d_off = {k: rel(g0b[k], g0[k]) for k in d_on}
+    bad = [(k, d_on[k], d_off[k]) for k in d_on if d_on[k] > 4 * d_off[k] + 0.1]
+    assert len(bad) <= 0.05 * len(d_on), bad[:5]
+    med = lambda d: sorted(d.values())[len(d) // 2]
+    assert med(d_on) <= 3 * med(d_off) + 2e-2, (med(d_on), med(d_off))
