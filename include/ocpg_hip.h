@@ -90,7 +90,9 @@ int ocpg_win_attn_bwd(const void* qkv, const float* bias, const float* biasT, co
                       float* dbiasT, int dtype, void* stream);
 
 /* Dynamic (per-query) mask head, forward -- replaces OCPG.dynamic_mask_with_coords + mask_heads_forward
- * (models/ocpg.py:475-549) for the reference's fixed head shape (2 layers, 16 channels, relative coordinates on):
+ * (models/ocpg.py:475-549) for the reference's fixed head shape (2 layers, 16 channels, relative coordinates on).
+ * Q counts the parameter sets per frame: the reference calls the head once per decoder layer on the SAME mask features
+ * (ocpg.py:339-349); passing Q = layers x queries does all of them in one launch.
  *   feats  [BT, C, H, W] fp32 mask features;  params [BT*Q, (C+2)*16 + 16*16 + 16 + 16] controller outputs in the
  *   reference's order (parse_dynamic_params, ocpg.py:552-569: W0 [16,(C+2)] incl. the x,y coordinate columns, W1 [16,16],
  *   b0, b1);  refpix [BT*Q, 2] reference point in INPUT pixels (ref_xy * (img_w, img_h));  stride = mask_feat_stride (8)

@@ -2,12 +2,17 @@
 //
 // Reference (models/ocpg.py:475-549): repeat the [b,t,C,h,w] mask features per query, append 2 relative-coordinate
 // channels (ref_xy * img_size - pixel centre, raw input pixels), reshape to [1, b*t*q*(C+2), h, w] (99 MB at
-// config #2) and run two grouped F.conv2d with the controller's weights, ReLU in between.
-// Here: one thread per pixel of a frame, all QT queries of the frame at once.  The features of the pixel are read
-// ONCE (coalesced, channel after channel); the per-query weights are wave-uniform, so they arrive through scalar
-// loads and every FMA is `v_fmac acc, s_weight, v_feature`; the coordinate channels are two extra FMAs from closed
-// form; layer 2 (16x16) runs on the 16 activations that are already in registers; nothing but the result (and the
-// layer-1 pre-activation, kept for the backward) is written.  HBM traffic = features in + 16 channels out per query.
+// config #2) and run two grouped F.conv2d with the controller's weights, ReLU in between -- once per decoder layer.
+// Here: ONE launch for all decoder layers (the caller passes the Q = layers x queries parameter sets of a frame together;
+// the features [BT, C, H, W] are shared).  A workgroup owns one query and a strip of pixels of its frame.  The query's
+// parameters (17.7 KB) are staged into LDS once, transposed to input-channel-major, and read back as broadcast
+// `ds_read_b128` (the 16 output weights of an input channel = 4 reads, every lane the same address -> conflict free).
+// Each lane carries PX pixels x 16 output channels in registers as 8 float2, so the inner loop is pure `v_pk_fma_f32`
+// (weights pair x broadcast feature); one LDS read feeds 4*PX FMAs and the kernel is bound by the fp32 VALU:
+// FLOPs per query-pixel = 2*16*(C+2) + 2*16*16; HBM bytes = features in (L2-resident across the queries of a frame)
+// + 2 x 16 channels out.  The coordinate channels are two FMAs from closed form; layer 2 (16x16) runs on the 16
+// activations already in registers; nothing but the result and the layer-1 pre-activation (kept for the backward) is
+// written.
 // Parameter layout per query (parse_dynamic_params, ocpg.py:552-569): [16 x (C+2)] W0 (row o: C feature weights, then
 // w_x, w_y), [16 x 16] W1, [16] b0, [16] b1.
 #include <hip/hip_runtime.h>
@@ -18,65 +23,132 @@
 namespace {
 
 constexpr int CH = 16;      // dynamic_mask_channels: fixed by the reference (pixel_shuffle(.., 4), literal c=16 at ocpg.py:528)
-constexpr int KC = 8;       // feature channels per scalar-load batch
+constexpr int NT = 128;     // threads per workgroup
+#ifndef DYNMASK_PX
+#define DYNMASK_PX 2        // pixels per lane in the large-map kernel (measured: 2/4 waves 130 us, 4/2 157 us, 8/2 152 us)
+#endif
+#ifndef DYNMASK_WPE
+#define DYNMASK_WPE 4       // waves per SIMD the register allocator is held to
+#endif
 
-template <int QT>
-__global__ __launch_bounds__(256) void dynmask_fwd(const float* __restrict__ feats, const float* __restrict__ params,
-                                                   const float* __restrict__ refpix, int Q, int C, int H, int W, int stride,
-                                                   float* __restrict__ out, float* __restrict__ pre1) {
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int PX>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DYNMASK_WPE, 8))) void dynmask_fwd(
+    const float* __restrict__ feats, const float* __restrict__ params, const float* __restrict__ refpix, int Q, int C, int H, int W,
+    int stride, float* __restrict__ out, float* __restrict__ pre1) {
+  extern __shared__ float4 smem4[];
+  float* smem = reinterpret_cast<float*>(smem4);
   const int HW = H * W;
   const int bt = blockIdx.z;
-  const int q0 = blockIdx.y * QT;
-  const int px = blockIdx.x * 256 + threadIdx.x;
-  const bool live = px < HW;
-  const int pxc = live ? px : HW - 1;
-  const int NP = (C + 2) * CH + CH * CH + 2 * CH;
-  const float* fb = feats + (long long)bt * C * HW + pxc;
-  float acc[QT][CH];
+  const long long n = (long long)bt * Q + blockIdx.y;
+  const int NW0 = (C + 2) * CH;
+  const int NP = NW0 + CH * CH + 2 * CH;
+  // LDS: W0 transposed to [C+2][16] (input channel major: the 16 outputs of one input channel are 4 aligned float4),
+  // W1 transposed to [16 in][16 out], b0 [16], b1 [16]
+  float* w0t = smem;
+  float* w1t = smem + (C + 2) * CH;
+  float* b0 = w1t + CH * CH;
+  float* b1 = b0 + CH;
+  {
+    const float* p = params + n * NP;
+    for (int i = threadIdx.x; i < NW0; i += NT) w0t[i] = p[(i & 15) * (C + 2) + (i >> 4)];       // i = k*16 + o
+    for (int i = threadIdx.x; i < CH * CH; i += NT) w1t[i] = p[NW0 + (i & 15) * CH + (i >> 4)];  // i = o*16 + o2
+    if (threadIdx.x < 2 * CH) b0[threadIdx.x] = p[NW0 + CH * CH + threadIdx.x];
+  }
+  __syncthreads();
+
+  const int px0 = blockIdx.x * (NT * PX) + threadIdx.x;
+  int pxc[PX];
 #pragma unroll
-  for (int q = 0; q < QT; ++q)
+  for (int j = 0; j < PX; ++j) {
+    const int px = px0 + j * NT;
+    pxc[j] = px < HW ? px : HW - 1;
+  }
+  const float* fb = feats + (long long)bt * C * HW;
+  v2f acc[PX][CH / 2];
 #pragma unroll
-    for (int o = 0; o < CH; ++o) acc[q][o] = 0.f;
-  for (int c0 = 0; c0 < C; c0 += KC) {
-    float f[KC];
+  for (int j = 0; j < PX; ++j)
 #pragma unroll
-    for (int k = 0; k < KC; ++k) f[k] = (c0 + k < C) ? fb[(long long)(c0 + k) * HW] : 0.f;
+    for (int o = 0; o < CH / 2; ++o) acc[j][o] = (v2f)(0.f);
+
+  // KC input channels per step; the next step's features are requested before this step's FMAs (register double buffer)
+  constexpr int KC = 4;
+  float fn[KC][PX];
 #pragma unroll
-    for (int q = 0; q < QT; ++q) {
-      if (q0 + q < Q) {      // uniform
-        const float* w = params + (long long)(bt * Q + q0 + q) * NP + c0;     // wave-uniform address -> scalar loads
+  for (int kk = 0; kk < KC; ++kk)
 #pragma unroll
-        for (int o = 0; o < CH; ++o) {
+    for (int j = 0; j < PX; ++j) fn[kk][j] = fb[(long long)(kk < C ? kk : C - 1) * HW + pxc[j]];
+  for (int k0 = 0; k0 < C; k0 += KC) {
+    float f[KC][PX];
 #pragma unroll
-          for (int k = 0; k < KC; ++k)
-            if (c0 + k < C) acc[q][o] += w[o * (C + 2) + k] * f[k];
+    for (int kk = 0; kk < KC; ++kk)
+#pragma unroll
+      for (int j = 0; j < PX; ++j) f[kk][j] = fn[kk][j];
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk) {
+      const int kn = k0 + KC + kk < C ? k0 + KC + kk : C - 1;          // clamped: the tail re-reads the last channel, unused
+#pragma unroll
+      for (int j = 0; j < PX; ++j) fn[kk][j] = fb[(long long)kn * HW + pxc[j]];
+    }
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk) {
+      if (k0 + kk < C) {                                                 // uniform; only the last step of a C % KC != 0 map
+        const float4* wr = reinterpret_cast<const float4*>(w0t + (k0 + kk) * CH);
+#pragma unroll
+        for (int o4 = 0; o4 < CH / 4; ++o4) {
+          const float4 wv = wr[o4];
+          const v2f wa = {wv.x, wv.y}, wb = {wv.z, wv.w};
+#pragma unroll
+          for (int j = 0; j < PX; ++j) {
+            const v2f ff = (v2f)(f[kk][j]);
+            acc[j][2 * o4] = __builtin_elementwise_fma(wa, ff, acc[j][2 * o4]);
+            acc[j][2 * o4 + 1] = __builtin_elementwise_fma(wb, ff, acc[j][2 * o4 + 1]);
+          }
         }
       }
     }
   }
-  const float xs = (float)((pxc % W) * stride + stride / 2), ys = (float)((pxc / W) * stride + stride / 2);
+
+  const float rx = refpix[2 * n], ry = refpix[2 * n + 1];
+  const v2f* wx2 = reinterpret_cast<const v2f*>(w0t + C * CH);
+  const v2f* wy2 = reinterpret_cast<const v2f*>(w0t + (C + 1) * CH);
+  const v2f* b02 = reinterpret_cast<const v2f*>(b0);
+  const v2f* b12 = reinterpret_cast<const v2f*>(b1);
 #pragma unroll
-  for (int q = 0; q < QT; ++q) {
-    if (q0 + q >= Q) continue;
-    const long long n = (long long)bt * Q + q0 + q;
-    const float* pw = params + n * NP;
-    const float relx = refpix[2 * n] - xs, rely = refpix[2 * n + 1] - ys;
-    const float* w1 = pw + (C + 2) * CH;
-    const float* b0 = w1 + CH * CH;
-    const float* b1 = b0 + CH;
+  for (int j = 0; j < PX; ++j) {
+    asm volatile("" ::: "memory");      // keep each pixel's epilogue (and its LDS reads) separate: no cross-pixel hoisting/spills
+    const int px = px0 + j * NT;
+    const bool live = px < HW;
+    const float relx = rx - (float)((pxc[j] % W) * stride + stride / 2);
+    const float rely = ry - (float)((pxc[j] / W) * stride + stride / 2);
     float hbuf[CH];
 #pragma unroll
-    for (int o = 0; o < CH; ++o) {
-      const float v = acc[q][o] + pw[o * (C + 2) + C] * relx + pw[o * (C + 2) + C + 1] * rely + b0[o];
-      if (live && pre1) pre1[(n * CH + o) * HW + px] = v;
-      hbuf[o] = v > 0.f ? v : 0.f;
+    for (int o = 0; o < CH / 2; ++o) {
+      const v2f v = acc[j][o] + wx2[o] * (v2f)(relx) + wy2[o] * (v2f)(rely) + b02[o];
+      if (live && pre1) {
+        pre1[(n * CH + 2 * o) * HW + px] = v.x;
+        pre1[(n * CH + 2 * o + 1) * HW + px] = v.y;
+      }
+      hbuf[2 * o] = v.x > 0.f ? v.x : 0.f;
+      hbuf[2 * o + 1] = v.y > 0.f ? v.y : 0.f;
     }
+    v2f r[CH / 2];
 #pragma unroll
-    for (int o2 = 0; o2 < CH; ++o2) {
-      float r = b1[o2];
+    for (int o2 = 0; o2 < CH / 2; ++o2) r[o2] = b12[o2];
 #pragma unroll
-      for (int o = 0; o < CH; ++o) r += w1[o2 * CH + o] * hbuf[o];
-      if (live) out[(n * CH + o2) * HW + px] = r;
+    for (int o = 0; o < CH; ++o) {
+      const v2f* wrow = reinterpret_cast<const v2f*>(w1t + o * CH);
+      const v2f hh = (v2f)(hbuf[o]);
+#pragma unroll
+      for (int o2 = 0; o2 < CH / 2; ++o2) r[o2] = __builtin_elementwise_fma(wrow[o2], hh, r[o2]);
+    }
+    if (live) {
+#pragma unroll
+      for (int o2 = 0; o2 < CH / 2; ++o2) {
+        out[(n * CH + 2 * o2) * HW + px] = r[o2].x;
+        out[(n * CH + 2 * o2 + 1) * HW + px] = r[o2].y;
+      }
     }
   }
 }
@@ -86,22 +158,22 @@ __global__ __launch_bounds__(256) void dynmask_fwd(const float* __restrict__ fea
 extern "C" int ocpg_dynmask_fwd_f32(const float* feats, const float* params, const float* refpix, int BT, int Q, int C, int H, int W,
                                     int stride, float* out, float* pre1, void* stream) {
   if (BT < 0 || Q <= 0 || C <= 0 || H <= 0 || W <= 0) return -1006;
+  if (Q > 65535 || BT > 65535) return -1008;
   if (BT == 0) return 0;
   if (!feats) return -1001;
   if (!params) return -1002;
   if (!refpix) return -1003;
   if (!out) return -1010;
+  const size_t lds = (size_t)(CH * (C + 2) + CH * CH + 2 * CH) * sizeof(float);
+  if (lds > 64 * 1024) return -1009;
   hipStream_t st = (hipStream_t)stream;
   const int HW = H * W;
-  const unsigned gx = (unsigned)((HW + 255) / 256);
-  if (Q % 5 == 0 || Q > 4) {
-    dynmask_fwd<5><<<dim3(gx, (Q + 4) / 5, BT), 256, 0, st>>>(feats, params, refpix, Q, C, H, W, stride, out, pre1);
-  } else if (Q > 2) {
-    dynmask_fwd<4><<<dim3(gx, (Q + 3) / 4, BT), 256, 0, st>>>(feats, params, refpix, Q, C, H, W, stride, out, pre1);
-  } else if (Q == 2) {
-    dynmask_fwd<2><<<dim3(gx, 1, BT), 256, 0, st>>>(feats, params, refpix, Q, C, H, W, stride, out, pre1);
+  if (HW >= 4 * NT * DYNMASK_PX) {
+    const unsigned gx = (unsigned)((HW + NT * DYNMASK_PX - 1) / (NT * DYNMASK_PX));
+    dynmask_fwd<DYNMASK_PX><<<dim3(gx, Q, BT), NT, lds, st>>>(feats, params, refpix, Q, C, H, W, stride, out, pre1);
   } else {
-    dynmask_fwd<1><<<dim3(gx, 1, BT), 256, 0, st>>>(feats, params, refpix, Q, C, H, W, stride, out, pre1);
+    const unsigned gx = (unsigned)((HW + NT - 1) / NT);
+    dynmask_fwd<1><<<dim3(gx, Q, BT), NT, lds, st>>>(feats, params, refpix, Q, C, H, W, stride, out, pre1);
   }
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;

@@ -267,17 +267,20 @@ class OCPG(nn.Module):
         tar = memory[0].shape[-2:]
         memory_fusion = sum(bicubic_resize(x.float(), tar) for x in memory)
         mask_features = memory_fusion.unflatten(0, (b, t))                         # [b, t, C, h, w]
-        seg_masks, seg_masks_shuffled = [], []
-        for lvl in range(nl):
-            params = self.controller(hs[lvl]).reshape(b, t * self.num_queries, -1)
-            refs = inter_references[lvl, ..., :2].reshape(b, t * self.num_queries, 2)
-            m = self.dynamic_mask_with_coords(mask_features, params, refs, targets)            # [b, (t q), 16, h, w]
-            seg_masks.append(m)
-            seg_masks_shuffled.append(F.pixel_shuffle(m.flatten(0, 1), 4).squeeze(1).view(b, t, self.num_queries, 4 * tar[0], 4 * tar[1]))
+        # all decoder layers in ONE head evaluation: the nl*q parameter sets of a frame sit next to each other ([b, t, l, q]),
+        # the mask features are shared (the reference loops over the layers, ocpg.py:339-349)
+        nq = self.num_queries
+        params = self.controller(hs.transpose(0, 1)).reshape(b, t * nl * nq, -1)                 # hs [l, b*t, q, c]
+        refs = inter_references[..., :2].transpose(0, 1).reshape(b, t * nl * nq, 2)
+        m_all = self.dynamic_mask_with_coords(mask_features, params, refs, targets)             # [b, (t l q), 16, h, w]
+        sh_all = F.pixel_shuffle(m_all.flatten(0, 1), 4).squeeze(1).view(b, t, nl, nq, 4 * tar[0], 4 * tar[1])
+        m_all = m_all.view(b, t, nl, nq, 16, tar[0], tar[1])
+        seg_masks = [m_all[:, :, l] for l in range(nl)]                                         # [b, t, q, 16, h, w] views
+        seg_masks_shuffled = [sh_all[:, :, l] for l in range(nl)]                               # [b, t, q, 4h, 4w] views
 
         if self.training:
             # in-forward matching (ocpg.py:352-366), all decoder layers in ONE tensor program
-            shuffled = torch.stack(seg_masks_shuffled)                                # [l, b, t, q, 4h, 4w]
+            shuffled = sh_all.permute(2, 0, 1, 3, 4, 5)                               # [l, b, t, q, 4h, 4w] (view)
             with torch.no_grad():
                 if self.aux_loss:
                     src_all = self.matcher.match_stacked(outputs_class, outputs_coord, shuffled, targets)      # [l, b]
@@ -297,7 +300,7 @@ class OCPG(nn.Module):
                 ls_features = torch.cat([img, ls_feat, sim.unsqueeze(2)], dim=2)    # [b, t, 12, 4h, 4w]  (same for every query)
 
                 # the matched query of every layer: one gather over [l, b, t, q, ...]
-                seg = torch.stack(seg_masks).view(nl, b, t, self.num_queries, 16, tar[0], tar[1])
+                seg = m_all.permute(2, 0, 1, 3, 4, 5, 6)                            # [l, b, t, q, 16, h, w] (view)
                 gi = src_all[:, :, None, None, None, None, None].expand(nl, b, t, 1, 16, tar[0], tar[1])
                 picked = torch.gather(seg, 3, gi)[:, :, :, 0].flatten(1, 2)         # [l, (b t), 16, h, w]
                 refined = self.mask_refine.forward_multi(list(picked.unbind(0)), features[:2], stacked=True)   # [l*(b t), 1, 2h, 2w]

@@ -28,6 +28,34 @@ def test_dynmask_mso(golden, dev):
     mc.check_dynmask_mso(golden("dynmask_mso"), dev, rtol=2e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("bt,q,c,h,w", [(2, 20, 256, 48, 80), (1, 5, 32, 40, 52), (3, 7, 10, 5, 9)])
+def test_dynmask_kernel_vs_oracle(dev, bt, q, c, h, w):
+    """ocpg_dynmask_fwd_f32 (+ its GEMM-shaped backward) against the literal restatement of ocpg.py:475-549 on the CPU:
+    the config-#2 map with all 4 decoder layers' queries in one launch (multi-pixel-per-lane kernel), a map with a
+    ragged last strip, and a tiny odd-channel case (one-pixel-per-lane kernel, C % 4 != 0)."""
+    from oracle import ocpg_ref
+    from ocpg_amd.models.ops.functions.dynmask_func import dynamic_mask
+    gen = torch.Generator().manual_seed(bt * 1000 + q)
+    feats = torch.randn(1, bt, c, h, w, generator=gen)
+    params = torch.randn(1, bt * q, (c + 2) * 16 + 256 + 32, generator=gen) * 0.1
+    refs = torch.rand(1, bt * q, 2, generator=gen)
+    go = torch.randn(1, bt * q, 16, h, w, generator=gen)
+    size = torch.tensor([h * 8 - 3, w * 8 - 5])
+    cfg = {"dynamic_mask_channels": 16, "controller_layers": 2}
+    f0, p0, r0 = (x.clone().requires_grad_(True) for x in (feats, params, refs))
+    want = ocpg_ref.dynamic_mask_with_coords(cfg, f0, p0, r0, [size])
+    (want * go).sum().backward()
+    f1, p1, r1 = (x.to(dev).requires_grad_(True) for x in (feats, params, refs))
+    refpix = r1 * torch.stack([size[1], size[0]]).float().to(dev)
+    got = dynamic_mask(f1[0], p1[0], refpix[0], 8)
+    (got * go[0].to(dev)).sum().backward()
+    scale = want.abs().max().item()
+    assert (got.cpu() - want[0]).abs().max().item() <= 2e-5 * scale + 1e-5
+    for a, b_, name in ((f1.grad, f0.grad, "feats"), (p1.grad, p0.grad, "params"), (r1.grad, r0.grad, "ref")):
+        err = (a.cpu() - b_).abs().max().item()
+        assert err <= 1e-4 * b_.abs().max().item() + 1e-5, (name, err, b_.abs().max().item())
+
+
 def test_matcher_criterion(golden, dev):
     mc.check_matcher_crit(golden("matcher_crit"), dev, rtol=2e-4, atol=2e-5)
 
