@@ -16,6 +16,8 @@ from torch import nn
 
 _ACTIVE = {}        # id(fp32 parameter) -> low-precision copy, valid inside one `scope`
 ENABLED = True      # A/B switch (tests compare against autocast's own per-op casts)
+GEMM_1X1 = True     # A/B switch: 1x1 convs of channels-last maps as hipBLASLt GEMMs instead of MIOpen convolutions
+SPLIT_K = True      # A/B switch: weight gradients over many rows as row-split batched GEMMs
 
 
 class FusedCast(torch.autograd.Function):
@@ -43,14 +45,129 @@ def lookup(p):
     return _ACTIVE.get(id(p), p) if _ACTIVE else p
 
 
-class Conv2d(nn.Conv2d):
+def _split_rows(m):
+    """Number of row chunks for the weight-gradient contraction over m rows (a divisor of m near m/1536, or 1)."""
+    s = _SPLITS.get(m)
+    if s is None:
+        s = 1
+        if m >= 4096:
+            want = m / 1536.0
+            cands = [d for d in range(max(2, m // 3072), min(128, m // 768) + 1) if m % d == 0]
+            if cands:
+                s = min(cands, key=lambda d: abs(d - want))
+        _SPLITS[m] = s
+    return s
+
+
+_SPLITS = {}
+
+
+def weight_grad(gy2, x2):
+    """gy2 [M, Co], x2 [M, Ci] (row-major, M = pixels or tokens, large) -> gy2^T x2 [Co, Ci].
+
+    As ONE GEMM this has a tiny output and a huge reduction dimension: hipBLASLt runs it on a handful of workgroups
+    (measured on MI355X, bf16: M=38400, 512x128 -> 138 us; M=153600, 256x64 -> 360 us; fp32 M=51000, 256x256 -> 201 us).
+    Split the rows into S chunks -> a batched GEMM with S x more workgroups + one small reduction: 25-36 us
+    (tools/bench_conv1x1_bwd.py)."""
+    m = gy2.shape[0]
+    s = _split_rows(m) if SPLIT_K else 1
+    if s == 1:
+        return torch.mm(gy2.t(), x2)
+    return torch.bmm(gy2.view(s, m // s, -1).transpose(1, 2), x2.view(s, m // s, -1)).sum(0)
+
+
+class Conv1x1AsGemm(torch.autograd.Function):
+    """A 1x1 / stride-1 convolution of a channels-last map IS the GEMM [N*H*W, Cin] x [Cin, Cout] on views (no copies).
+    Measured on MI355X at the ResNet-101 shapes of config #2 (10 frames, bf16, GPU-busy time, tools/bench_conv1x1*.py):
+    forward 14-18 us against MIOpen's 58-125 us (layers 3/4), input gradient 14-29 us against 26-95 us, weight gradient
+    (split over the rows, `weight_grad`) 23-36 us against 61-81 us.  One autograd node."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        n, c, h, wd = x.shape
+        x2 = x.permute(0, 2, 3, 1).reshape(n * h * wd, c)
+        w2 = w.reshape(w.shape[0], c)
+        y2 = torch.mm(x2, w2.t()) if bias is None else torch.addmm(bias, x2, w2.t())
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y2.view(n, h, wd, w.shape[0]).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        n, c, h, wd = x.shape
+        co = w.shape[0]
+        gy2 = gy.permute(0, 2, 3, 1).reshape(n * h * wd, co)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.mm(gy2, w.reshape(co, c)).view(n, h, wd, c).permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            gw = weight_grad(gy2, x.permute(0, 2, 3, 1).reshape(n * h * wd, c)).view(w.shape)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy2.sum(0)
+        return gx, gw, gb
+
+
+class TokenLinearFunction(torch.autograd.Function):
+    """y = x2 W^T + b for MANY rows (tokens): same GEMMs as F.linear, but the weight gradient goes through `weight_grad`."""
+
+    @staticmethod
+    def forward(ctx, x2, w, bias):
+        ctx.save_for_backward(x2, w)
+        ctx.has_bias = bias is not None
+        return torch.mm(x2, w.t()) if bias is None else torch.addmm(bias, x2, w.t())
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = torch.mm(gy, w) if ctx.needs_input_grad[0] else None
+        gw = weight_grad(gy, x2) if ctx.needs_input_grad[1] else None
+        gb = gy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+def linear(x, w, b):
+    """F.linear; on the GPU, with >= 8192 rows and a weight that needs a gradient, through TokenLinearFunction."""
+    k = x.shape[-1]
+    if SPLIT_K and x.is_cuda and w.requires_grad and x.numel() >= 8192 * k and torch.is_grad_enabled():
+        if torch.is_autocast_enabled("cuda"):
+            dt = torch.get_autocast_dtype("cuda")
+            x, w, b = x.to(dt), w.to(dt), None if b is None else b.to(dt)
+        if x.dtype == w.dtype:
+            return TokenLinearFunction.apply(x.reshape(-1, k), w, b).view(*x.shape[:-1], w.shape[0])
+    return F.linear(x, w, b)
+
+
+class TokenLinear(nn.Linear):
+    """nn.Linear for modules that run OUTSIDE autocast (fp32 islands: MSDeformAttn's projections over all H*W tokens)."""
+
     def forward(self, x):
-        return self._conv_forward(x, lookup(self.weight), None if self.bias is None else lookup(self.bias))
+        return linear(x, self.weight, self.bias)
+
+
+class Conv2d(nn.Conv2d):
+    def _is_pointwise(self):
+        r = self.__dict__.get("_pointwise")
+        if r is None:
+            r = self.__dict__["_pointwise"] = (self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0)
+                                               and self.groups == 1 and self.padding_mode == "zeros")
+        return r
+
+    def forward(self, x):
+        w, b = lookup(self.weight), None if self.bias is None else lookup(self.bias)
+        if GEMM_1X1 and x.is_cuda and x.dim() == 4 and self._is_pointwise() and x.is_contiguous(memory_format=torch.channels_last):
+            if torch.is_autocast_enabled("cuda"):
+                dt = torch.get_autocast_dtype("cuda")
+                x, w, b = x.to(dt), w.to(dt), None if b is None else b.to(dt)
+            if x.dtype == w.dtype:
+                return Conv1x1AsGemm.apply(x, w, b)
+        return self._conv_forward(x, w, b)
 
 
 class Linear(nn.Linear):
     def forward(self, x):
-        return F.linear(x, lookup(self.weight), None if self.bias is None else lookup(self.bias))
+        return linear(x, lookup(self.weight), None if self.bias is None else lookup(self.bias))
 
 
 def cast_params_of(module):

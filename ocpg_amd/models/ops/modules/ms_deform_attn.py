@@ -11,6 +11,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ...amp_cache import TokenLinear
 from ..functions import MSDeformAttnFunction
 
 
@@ -29,10 +30,10 @@ class MSDeformAttn(nn.Module):
             warnings.warn("d_model // n_heads should be a power of 2 (the fast HIP kernel needs it; others take the generic kernel)")
         self.im2col_step = 64
         self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
-        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
-        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
-        self.value_proj = nn.Linear(d_model, d_model)
-        self.output_proj = nn.Linear(d_model, d_model)
+        self.sampling_offsets = TokenLinear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = TokenLinear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = TokenLinear(d_model, d_model)
+        self.output_proj = TokenLinear(d_model, d_model)
         self._reset_parameters()
 
     def _reset_parameters(self):

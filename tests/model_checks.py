@@ -29,10 +29,21 @@ def text_for(B, device):
     return PrecomputedText(f.to(device), s.to(device), m.to(device))
 
 
-def run_train_step(g, tag, device, rtol, atol):
+def to_channels_last(model):
+    """bench.py's layout: every Conv2d in channels-last (the ResNet body then runs NHWC end to end: fused frozen-BN NHWC
+    kernels, 1x1 convs as GEMMs)."""
+    for m in model.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            m.to(memory_format=torch.channels_last)
+    return model
+
+
+def run_train_step(g, tag, device, rtol, atol, channels_last=False):
     from ocpg_amd.util.misc import NestedTensor
     meta = g.meta
     args, model, crit = build_product(meta, device)
+    if channels_last:
+        to_channels_last(model)
     B, T, H, W = meta["B"], meta["T"], meta["H"], meta["W"]
     x, mask, targets = cases.e2e_inputs(B, T, H, W, meta[f"{tag}_sizes"], device)
     model.train(), crit.train()

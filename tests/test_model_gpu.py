@@ -67,6 +67,59 @@ def test_train_step_matches_reference(golden, dev, tag):
     print(res)
 
 
+def test_train_step_channels_last_layout(golden, dev):
+    """The bench layout (channels-last convs: NHWC frozen-BN kernels, 1x1 convs as hipBLASLt GEMMs) against the same
+    reference vectors, fp32, same bounds."""
+    model_checks.run_train_step(golden("e2e_tiny"), "nopad", dev, rtol=1e-3, atol=1e-4, channels_last=True)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("bias", [False, True])
+def test_pointwise_conv_as_gemm(dev, dtype, bias):
+    """amp_cache.Conv2d's GEMM path for 1x1/stride-1 convs of channels-last maps == the convolution (MIOpen) path."""
+    from ocpg_amd.models import amp_cache
+    torch.manual_seed(0)
+    conv = amp_cache.Conv2d(96, 160, 1, bias=bias).to(dev, dtype)
+    x = torch.randn(3, 96, 13, 17, device=dev, dtype=dtype).contiguous(memory_format=torch.channels_last)
+    go = torch.randn(3, 160, 13, 17, device=dev, dtype=dtype).contiguous(memory_format=torch.channels_last)
+    res = []
+    for on in (True, False):
+        amp_cache.GEMM_1X1 = on
+        try:
+            xi = x.clone().requires_grad_(True)
+            conv.zero_grad()
+            y = conv(xi)
+            assert (type(y.grad_fn).__name__ == "Conv1x1AsGemmBackward") == on
+            y.backward(go)
+            res.append([y.detach().float(), xi.grad.float(), conv.weight.grad.float()] + ([conv.bias.grad.float()] if bias else []))
+        finally:
+            amp_cache.GEMM_1X1 = True
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for a, b_ in zip(*res):
+        assert a.shape == b_.shape and (a - b_).abs().max().item() <= tol * b_.abs().max().item() + 1e-6
+
+
+@pytest.mark.parametrize("dtype,rows", [(torch.float32, 10200), (torch.bfloat16, 9600), (torch.float32, 8191 * 2 + 1)])
+def test_token_linear_row_split_weight_gradient(dev, dtype, rows):
+    """amp_cache.linear (row-split batched GEMM for the weight gradient) == F.linear, incl. a row count with no divisor."""
+    from ocpg_amd.models import amp_cache
+    import torch.nn.functional as F
+    torch.manual_seed(1)
+    x = torch.randn(2, rows // 2, 64, device=dev, dtype=dtype)
+    w = (torch.randn(48, 64, device=dev, dtype=dtype) * 0.1).requires_grad_(True)
+    b = torch.randn(48, device=dev, dtype=dtype).requires_grad_(True)
+    go = torch.randn(2, rows // 2, 48, device=dev, dtype=dtype)
+    res = []
+    for fn in (amp_cache.linear, F.linear):
+        xi = x.clone().requires_grad_(True)
+        y = fn(xi, w, b)
+        res.append([y.detach().float()] + [g.float() for g in torch.autograd.grad((y.float() * go.float()).sum(), (xi, w, b))])
+    assert type(amp_cache.linear(x.clone().requires_grad_(True), w, b).grad_fn).__name__ == "ViewBackward0"
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    for a, b_ in zip(*res):
+        assert (a - b_).abs().max().item() <= tol * b_.abs().max().item() + 1e-6
+
+
 @pytest.mark.parametrize("tag", ["nopad", "pad"])
 def test_eval_tail_matches_reference(golden, dev, tag):
     model_checks.run_eval(golden("e2e_tiny"), tag, dev, rtol=1e-3, atol=1e-4)
