@@ -47,7 +47,7 @@ def synthetic_batch(n_clips, device, seed, roberta=False):
     like collate_fn does (util/misc.py:302), with the padding mask set."""
     from synth import synthetic_targets
     from ocpg_amd.models.text_encoder.text_encoder import PrecomputedText
-    from ocpg_amd.util.misc import NestedTensor
+    from ocpg_amd.util.misc import NestedTensor, tag_rect_mask
     g = torch.Generator(device="cpu").manual_seed(seed)
     hp, wp = (HEIGHT + 31) // 32 * 32, (WIDTH + 31) // 32 * 32
     x = torch.zeros(n_clips, T_FRAMES, 3, hp, wp)
@@ -63,7 +63,9 @@ def synthetic_batch(n_clips, device, seed, roberta=False):
         text = PrecomputedText(torch.randn(n_clips, 9, 768, generator=g).to(device), torch.randn(n_clips, 768, generator=g).to(device),
                                torch.zeros(n_clips, 9, dtype=torch.bool, device=device))
     targets = synthetic_targets(n_clips, T_FRAMES, HEIGHT, WIDTH, device)
-    return (lambda: NestedTensor(x.clone(), mask.clone())), text, targets
+    # the collate step knows every frame's valid extent on the host (as util.misc.collate_fn does) and says so on the mask
+    valid_hw = [(HEIGHT, WIDTH)] * (n_clips * T_FRAMES)
+    return (lambda: NestedTensor(x.clone(), tag_rect_mask(mask.clone(), valid_hw))), text, targets
 
 
 def make_optimizer(model, args):
@@ -89,8 +91,7 @@ def forward_backward(model, criterion, samples, text, targets, amp_dtype, num_bo
         if num_boxes is not None:
             out["num_boxes"] = num_boxes
         loss_dict, *_ = criterion(out, targets)
-        wd = criterion.weight_dict
-        loss = sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)
+        loss = criterion.weighted_sum(loss_dict)        # = sum(loss_dict[k] * weight_dict[k]) (engine.py:56), one reduction
     (scaler.scale(loss) if scaler is not None else loss).backward()
     if keep is not None:        # static graph outputs (the usual whole-network-capture rule: keep them referenced)
         keep.update(out=out, loss_dict=loss_dict, loss=loss)

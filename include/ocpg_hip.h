@@ -100,6 +100,15 @@ int ocpg_win_attn_bwd(const void* qkv, const float* bias, const float* biasT, co
 int ocpg_dynmask_fwd_f32(const float* feats, const float* params, const float* refpix, int BT, int Q, int C, int H, int W,
                          int stride, float* out, float* pre1, void* stream);
 
+/* 3x3 convolution of channels-last maps as one dense GEMM -- replaces the conv kernels behind nn.Conv2d(k=3) in the ResNet
+ * body (torchvision Bottleneck.conv2 via models/backbone.py:86-117) and the neck (models/ocpg.py:118-126); the GEMM itself
+ * is hipBLASLt's.  Geometry: kernel 3x3, padding == dil, stride in {1,2}; Ho = (H-1)/stride + 1, Wo likewise.
+ *   im2col: x [N,H,W,C] -> cols [N*Ho*Wo, 9*C], column order (ky, kx, c) = the physical order of a channels-last weight
+ *   col2im: dcols [N*Ho*Wo, 9*C] -> dx [N,H,W,C] (the adjoint: every dx element fully written, fp32 accumulation)
+ * dtype: 0 fp32, 1 bf16, 2 fp16; C * sizeof(elem) must be a multiple of 16. */
+int ocpg_im2col3x3_nhwc(const void* x, int N, int H, int W, int C, int stride, int dil, void* cols, int dtype, void* stream);
+int ocpg_col2im3x3_nhwc(const void* dcols, int N, int H, int W, int C, int stride, int dil, void* dx, int dtype, void* stream);
+
 /* library / build identification: returns e.g. "ocpg_hip gfx950 r1" */
 const char* ocpg_hip_version(void);
 

@@ -25,6 +25,8 @@ SIGNATURES = {
     "ocpg_bn_act_fwd": [_vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _int, ctypes.c_longlong, _int, _int, _vp],
     "ocpg_bn_act_bwd": [_vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _int, ctypes.c_longlong, _int, _int, _vp],
     "ocpg_dynmask_fwd_f32": [_vp, _vp, _vp] + [_int] * 6 + [_vp, _vp, _vp],
+    "ocpg_im2col3x3_nhwc": [_vp] + [_int] * 6 + [_vp, _int, _vp],
+    "ocpg_col2im3x3_nhwc": [_vp] + [_int] * 6 + [_vp, _int, _vp],
     "ocpg_win_attn_fwd": [_vp, _vp, _vp, ctypes.c_float] + [_int] * 5 + [_vp, _vp, _int, _vp],
     "ocpg_win_attn_bwd": [_vp, _vp, _vp, _vp, ctypes.c_float] + [_int] * 5 + [_vp] * 6 + [_int, _vp],
 }

@@ -9,15 +9,19 @@ through `lookup`.  Outside autocast nothing changes (the table is empty and `loo
 Numerically identical to autocast's own per-op casts.
 """
 import contextlib
+import os
 
 import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .ops.functions import conv_gemm_func
+
 _ACTIVE = {}        # id(fp32 parameter) -> low-precision copy, valid inside one `scope`
 ENABLED = True      # A/B switch (tests compare against autocast's own per-op casts)
-GEMM_1X1 = True     # A/B switch: 1x1 convs of channels-last maps as hipBLASLt GEMMs instead of MIOpen convolutions
-SPLIT_K = True      # A/B switch: weight gradients over many rows as row-split batched GEMMs
+GEMM_1X1 = os.environ.get("OCPG_GEMM_1X1", "1") != "0"     # A/B switch: 1x1 convs of channels-last maps as hipBLASLt GEMMs instead of MIOpen convolutions
+GEMM_3X3 = os.environ.get("OCPG_GEMM_3X3", "0") != "0"     # A/B switch: 3x3 convs of channels-last maps as HIP im2col + one hipBLASLt GEMM
+SPLIT_K = os.environ.get("OCPG_SPLIT_K", "1") != "0"      # A/B switch: weight gradients over many rows as row-split batched GEMMs
 
 
 class FusedCast(torch.autograd.Function):
@@ -162,6 +166,12 @@ class Conv2d(nn.Conv2d):
                 x, w, b = x.to(dt), w.to(dt), None if b is None else b.to(dt)
             if x.dtype == w.dtype:
                 return Conv1x1AsGemm.apply(x, w, b)
+        elif GEMM_3X3 and x.is_cuda and conv_gemm_func.eligible(x, self):
+            if torch.is_autocast_enabled("cuda"):
+                dt = torch.get_autocast_dtype("cuda")
+                x, w, b = x.to(dt), w.to(dt), None if b is None else b.to(dt)
+            if x.dtype == w.dtype and conv_gemm_func.eligible(x, self):
+                return conv_gemm_func.conv3x3_gemm(x, w, b, self.stride[0], self.dilation[0])
         return self._conv_forward(x, w, b)
 
 

@@ -13,7 +13,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..util.misc import NestedTensor
+from ..util.misc import NestedTensor, mask_key, resize_mask
 from . import amp_cache
 from .ops.functions.bn_act_func import frozen_bn_act
 from .position_encoding import build_position_encoding
@@ -139,7 +139,7 @@ class Backbone(nn.Module):
         assert m is not None
         out = {}
         for name, x in self.body(tensor_list.tensors).items():
-            mask = F.interpolate(m[None].float(), size=x.shape[-2:]).to(torch.bool)[0]
+            mask = resize_mask(m, x.shape[-2:])
             out[name] = NestedTensor(x, mask)
         return out
 
@@ -153,7 +153,10 @@ class Joiner(nn.Sequential):
     def forward(self, tensor_list: NestedTensor):
         # NB (reference quirk, backbone.py:111-112): the caller's NestedTensor is folded IN PLACE to [(b t), ...]
         tensor_list.tensors = tensor_list.tensors.flatten(0, 1)
+        key = mask_key(tensor_list.mask)
         tensor_list.mask = tensor_list.mask.flatten(0, 1)
+        if key is not None:
+            tensor_list.mask._ocpg_key = key
         feats: List[NestedTensor] = []
         pos = []
         for _, x in self[0](tensor_list).items():

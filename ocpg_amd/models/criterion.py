@@ -235,12 +235,29 @@ class SetCriterion(nn.Module):
             warm = self._warm(len(layers)).to(outputs["pred_masks_low"].device)
             d, maps = self._masks_stacked(stacked("pred_masks"), stacked("pred_masks_low"), outputs["ls_features"], targets, num_boxes, warm)
             per_layer.update(d)
-        order = ["loss_ce", "loss_bbox", "loss_giou", "loss_proj", "loss_mask", "loss_lst", "loss_proj_low", "loss_mask_low", "loss_lst_low"]
-        for k in order:
-            if k in per_layer:
-                losses[k] = per_layer[k][0]
-        for i in range(len(aux)):
-            for k in order:
-                if k in per_layer:
-                    losses[f"{k}_{i}"] = per_layer[k][i + 1]
+        order = [k for k in ("loss_ce", "loss_bbox", "loss_giou", "loss_proj", "loss_mask", "loss_lst", "loss_proj_low", "loss_mask_low",
+                             "loss_lst_low") if k in per_layer]
+        table = torch.stack([per_layer[k] for k in order])                     # [n_losses, Lr]
+        names = [[k if i == 0 else f"{k}_{i - 1}" for i in range(len(layers))] for k in order]
+        for i in range(len(layers)):            # key order of the reference: the main layer's losses, then aux 0, aux 1, ...
+            for j, row in enumerate(names):
+                losses[row[i]] = table[j, i]
+        # the weighted total the training loop forms next (engine.py:56), as ONE reduction over the table instead of 36
+        # scalar multiplies and adds (and, in backward, 36 select-scatter nodes)
+        self._last = (losses, table, names)
         return (losses,) + maps
+
+    def weighted_sum(self, loss_dict):
+        """sum(loss_dict[k] * weight_dict[k] for k in loss_dict if k in weight_dict), the reference training loop's total
+        (engine.py:55-56); for the dict this criterion just returned it is one multiply + one sum over the loss table."""
+        last = getattr(self, "_last", None)
+        if last is None or last[0] is not loss_dict:
+            return sum(loss_dict[k] * self.weight_dict[k] for k in loss_dict if k in self.weight_dict)
+        _, table, names = last
+        key = (tuple(map(tuple, names)), str(table.device))
+        cache = self.__dict__.setdefault("_weight_tables", {})
+        w = cache.get(key)
+        if w is None:       # weight_dict is fixed at construction (models/ocpg.py:573-594)
+            w = cache[key] = torch.tensor([[float(self.weight_dict.get(n, 0.0)) for n in row] for row in names], dtype=torch.float32,
+                                          device=table.device)
+        return (table.float() * w).sum()

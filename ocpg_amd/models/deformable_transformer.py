@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..util.misc import inverse_sigmoid
+from ..util.misc import inverse_sigmoid, mask_key, memo
 from . import amp_cache
 from .attention import MultiheadAttention
 from .ops.modules import MSDeformAttn
@@ -80,7 +80,8 @@ class DeformableTransformerEncoder(nn.Module):
         return ref[:, :, None] * valid_ratios[:, None]
 
     def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None):
-        ref = self.get_reference_points(spatial_shapes, valid_ratios, src.device)
+        ref = memo("enc_ref_points", getattr(valid_ratios, "_ocpg_key", None), src.device,
+                   lambda: self.get_reference_points(spatial_shapes, valid_ratios, src.device))
         out = src
         for layer in self.layers:
             out = layer(out, pos, ref, spatial_shapes, level_start_index, padding_mask)
@@ -220,7 +221,11 @@ class DeformableTransformer(nn.Module):
         mask = torch.cat([m.flatten(1) for m in masks], 1)
         pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[l].view(1, 1, -1) for l, p in enumerate(pos_embeds)], 1)
         spatial_shapes, level_start_index = self._level_geometry(tuple(shapes_host), dev)
-        valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
+        keys = tuple(mask_key(m) for m in masks)
+        keys = None if any(k is None for k in keys) else keys
+        valid_ratios = memo("valid_ratios", keys, dev, lambda: torch.stack([self.get_valid_ratio(m) for m in masks], 1))
+        if keys is not None:
+            valid_ratios._ocpg_key = keys
 
         memory = self.encoder(src, spatial_shapes, level_start_index, valid_ratios, pos, mask)
 

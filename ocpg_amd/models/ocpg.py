@@ -21,7 +21,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..util.misc import NestedTensor, inverse_sigmoid, nested_tensor_from_videos_list
+from ..util.misc import NestedTensor, inverse_sigmoid, nested_tensor_from_videos_list, resize_mask
 from . import amp_cache
 from .backbone import build_backbone
 from .criterion import SetCriterion
@@ -235,7 +235,7 @@ class OCPG(nn.Module):
             srcs.append(src), masks.append(mask), poses.append(pos_l)
         for l in range(len(srcs), self.num_feature_levels):
             src = self.input_proj[l](features[-1].tensors if l == n_scales else srcs[-1])
-            mask = F.interpolate(samples.mask[None].float(), size=src.shape[-2:]).to(torch.bool)[0]
+            mask = resize_mask(samples.mask, src.shape[-2:])
             pos_l = self.backbone[1](NestedTensor(src, mask)).to(src.dtype)
             src, high_filter = self._fuse_level(l, src, b, t, text_words, text_pad, text_pos, high_filter)
             srcs.append(src), masks.append(mask), poses.append(pos_l)

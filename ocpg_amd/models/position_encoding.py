@@ -4,6 +4,8 @@ import math
 import torch
 from torch import nn
 
+from ..util.misc import mask_key, memo
+
 
 _FREQ_CACHE = {}
 
@@ -55,6 +57,10 @@ class PositionEmbeddingSine2D(nn.Module):
     def forward(self, tensor_list):
         mask = tensor_list.mask                                           # [B, H, W]
         assert mask is not None
+        cfg = ("pos2d", self.num_pos_feats, float(self.temperature), self.normalize, float(self.scale))
+        return memo(cfg, mask_key(mask), mask.device, lambda: self._encode(mask))
+
+    def _encode(self, mask):
         valid = ~mask
         y = valid.cumsum(1, dtype=torch.float32)
         x = valid.cumsum(2, dtype=torch.float32)

@@ -6,7 +6,22 @@ def box_area(b):
     return (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
 
 
+_TO_XYXY = {}
+
+
 def box_cxcywh_to_xyxy(x):
+    """[..., (cx, cy, w, h)] -> [..., (x0, y0, x1, y1)] (util/box_ops.py:9-13).
+
+    fp32 GPU tensors: ONE matmul with a constant 4x4 (one kernel forward, one backward, instead of unbind + 4 elementwise
+    + stack and their 9 backward nodes; the conversion is called ~10x per step on tiny tensors, the step is launch-bound).
+    Bit-identical: every output is cx + (+-0.5) * w, the other two products are exact zeros."""
+    if x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == 4:
+        m = _TO_XYXY.get(x.device)
+        if m is None:
+            m = _TO_XYXY[x.device] = torch.tensor([[1, 0, 1, 0], [0, 1, 0, 1], [-0.5, 0, 0.5, 0], [0, -0.5, 0, 0.5]], dtype=torch.float32,
+                                                  device=x.device)
+        with torch.autocast(device_type="cuda", enabled=False):
+            return torch.matmul(x, m)
     cx, cy, w, h = x.unbind(-1)
     return torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], dim=-1)
 

@@ -5,11 +5,60 @@ nested_tensor_from_tensor_list :318-352, nested_tensor_from_videos_list :354-377
 is_dist_avail_and_initialized / get_world_size) -- only what the per-clip path needs; logging, checkpoint
 and all-gather helpers of that file are out of scope.
 """
+from collections import OrderedDict
 from typing import List, Optional
 
 import torch
 import torch.distributed as dist
+import torch.nn.functional as F
 from torch import Tensor
+
+# ---- memoisation of everything that depends ONLY on the padding mask -----------------------------------------------
+# A batch's padding mask is "valid rectangle [0:h_i, 0:w_i] per image" and the collate functions below know (h_i, w_i) on
+# the host.  They tag the mask tensor with that description (`_ocpg_key`); position encodings, per-level masks, valid
+# ratios and the encoder's reference grid are pure functions of it and are computed ONCE per distinct description
+# (reference: recomputed every forward, ~230 small kernels: position_encoding.py:52-84, backbone.py:97-103,
+# deformable_transformer.py:125-131,268-281).  Untagged masks (a caller-built NestedTensor) take the uncached path.
+MEMO_ENABLED = True
+_MEMO = OrderedDict()
+_MEMO_CAP = 512
+
+
+def tag_rect_mask(mask: Tensor, valid_hw) -> Tensor:
+    """Declare: mask[..., y, x] == (y >= h_i or x >= w_i) for image i in row-major order of the leading axes."""
+    mask._ocpg_key = ("rect", int(mask.shape[-2]), int(mask.shape[-1]), tuple((int(h), int(w)) for h, w in valid_hw))
+    return mask
+
+
+def mask_key(mask):
+    return getattr(mask, "_ocpg_key", None) if MEMO_ENABLED else None
+
+
+def memo(tag, key, device, compute):
+    """compute() (tensors without autograd history, never modified in place downstream), cached on (tag, key, device)."""
+    if key is None:
+        return compute()
+    k = (tag, key, str(device))
+    v = _MEMO.get(k)
+    if v is None:
+        with torch.no_grad():
+            v = compute()
+        _MEMO[k] = v
+        if len(_MEMO) > _MEMO_CAP:
+            _MEMO.popitem(last=False)
+    else:
+        _MEMO.move_to_end(k)
+    return v
+
+
+def resize_mask(mask: Tensor, size) -> Tensor:
+    """Nearest-neighbour resize of a [N,H,W] padding mask to a feature level (backbone.py:100-102), memoised."""
+    size = (int(size[0]), int(size[1]))
+    key = mask_key(mask)
+    out = memo(("resize", size), key, mask.device, lambda: F.interpolate(mask[None].float(), size=size).to(torch.bool)[0])
+    if key is not None:
+        out._ocpg_key = ("resized", key, size)
+    return out
 
 
 class NestedTensor:
@@ -20,7 +69,10 @@ class NestedTensor:
         self.mask = mask
 
     def to(self, device):
-        return NestedTensor(self.tensors.to(device), None if self.mask is None else self.mask.to(device))
+        mask = None if self.mask is None else self.mask.to(device)
+        if mask is not None and hasattr(self.mask, "_ocpg_key"):
+            mask._ocpg_key = self.mask._ocpg_key
+        return NestedTensor(self.tensors.to(device), mask)
 
     def decompose(self):
         return self.tensors, self.mask
@@ -49,7 +101,7 @@ def nested_tensor_from_tensor_list(tensor_list: List[Tensor], size_divisibility:
     for i, t in enumerate(tensor_list):
         out[i, : t.shape[0], : t.shape[1], : t.shape[2]] = t
         mask[i, : t.shape[1], : t.shape[2]] = False
-    return NestedTensor(out, mask)
+    return NestedTensor(out, tag_rect_mask(mask, [(t.shape[1], t.shape[2]) for t in tensor_list]))
 
 
 def nested_tensor_from_videos_list(videos_list: List[Tensor], size_divisibility: int = 1) -> NestedTensor:
@@ -64,7 +116,8 @@ def nested_tensor_from_videos_list(videos_list: List[Tensor], size_divisibility:
     for i, v in enumerate(videos_list):
         out[i, : v.shape[0], :, : v.shape[2], : v.shape[3]] = v
         mask[i, : v.shape[0], : v.shape[2], : v.shape[3]] = False
-    return NestedTensor(out, mask)
+    valid_hw = [(v.shape[2], v.shape[3]) if j < v.shape[0] else (0, 0) for v in videos_list for j in range(t)]
+    return NestedTensor(out, tag_rect_mask(mask, valid_hw))
 
 
 def collate_fn(batch):
@@ -74,8 +127,12 @@ def collate_fn(batch):
 
 
 def inverse_sigmoid(x: Tensor, eps: float = 1e-5) -> Tensor:
-    x = x.clamp(min=0, max=1)
-    return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
+    """log(x / (1 - x)) with both sides clamped at eps (util/misc.py:560-564).  One fused op (aten::logit clamps x to
+    [eps, 1-eps] and evaluates the same quotient): bit-identical inside (eps, 1-eps).  At the clamped ends the reference
+    evaluates log(eps / 1) resp. log(1 / eps) = -+11.5129 and this log(eps / (1 - eps)) resp. log((1 - eps) / fl(eps)) =
+    -11.5129 / +11.5116 (fp32 rounding of 1 - eps): <= 1.4e-3 apart where the following sigmoid has slope 1e-5, i.e. <= 2e-8
+    on any box coordinate; both have zero gradient there."""
+    return torch.logit(x, eps)
 
 
 def is_dist_avail_and_initialized() -> bool:

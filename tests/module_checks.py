@@ -198,6 +198,10 @@ def check_matcher_crit(g, dev, rtol=1e-4, atol=1e-5):
     assert set("loss_" + k for k in losses) == {k for k in g.keys() if k.startswith("loss_")}
     total = sum(losses[k] * wd[k] for k in losses if k in wd)
     close(total, g["total"], rtol, atol, "total")
+    # the one-reduction total the bench loop uses, on the criterion's own dict and (generic path) on a copy of it
+    close(crit.weighted_sum(losses), g["total"], rtol, atol, "weighted_sum")
+    close(crit.weighted_sum(dict(losses)), g["total"], rtol, atol, "weighted_sum (foreign dict)")
+    total = crit.weighted_sum(losses)
     leaves = [out["pred_logits"], out["pred_boxes"], out["pred_masks"], out["pred_masks_low"], out["ls_features"]]
     grads = torch.autograd.grad(total, leaves)
     for gr, k in zip(grads, ("g_logits", "g_boxes", "g_pm", "g_pml", "g_ls")):

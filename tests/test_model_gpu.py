@@ -99,6 +99,34 @@ def test_pointwise_conv_as_gemm(dev, dtype, bias):
         assert a.shape == b_.shape and (a - b_).abs().max().item() <= tol * b_.abs().max().item() + 1e-6
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("stride,dil,bias,hw", [(1, 1, False, (13, 17)), (2, 1, True, (13, 16)), (2, 1, False, (12, 17)), (1, 2, True, (9, 11))])
+def test_conv3x3_as_im2col_gemm(dev, dtype, stride, dil, bias, hw):
+    """amp_cache.Conv2d's im2col (HIP) + GEMM path for 3x3 convs of channels-last maps == the convolution (MIOpen) path:
+    odd/even sizes under stride 2, dilation 2 (the reference's --dilation layer4), bias, three storage types."""
+    from ocpg_amd.models import amp_cache
+    torch.manual_seed(0)
+    conv = amp_cache.Conv2d(32, 48, 3, stride=stride, padding=dil, dilation=dil, bias=bias).to(dev, dtype).to(memory_format=torch.channels_last)
+    x = torch.randn(3, 32, *hw, device=dev, dtype=dtype).contiguous(memory_format=torch.channels_last)
+    from ocpg_amd.models.ops.functions import conv_gemm_func
+    res = []
+    for on in (True, False):
+        amp_cache.GEMM_3X3 = conv_gemm_func.ALWAYS = on
+        try:
+            xi = x.clone().requires_grad_(True)
+            conv.zero_grad()
+            y = conv(xi)
+            assert (type(y.grad_fn).__name__ == "Conv3x3AsGemmBackward") == on
+            go = torch.randn(y.shape, device=dev, dtype=dtype, generator=torch.Generator(device=dev).manual_seed(5))
+            y.backward(go)
+            res.append([y.detach().float(), xi.grad.float(), conv.weight.grad.float()] + ([conv.bias.grad.float()] if bias else []))
+        finally:
+            amp_cache.GEMM_3X3, conv_gemm_func.ALWAYS = True, False
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    for a, b_ in zip(*res):
+        assert a.shape == b_.shape and (a - b_).abs().max().item() <= tol * b_.abs().max().item() + 1e-6
+
+
 @pytest.mark.parametrize("dtype,rows", [(torch.float32, 10200), (torch.bfloat16, 9600), (torch.float32, 8191 * 2 + 1)])
 def test_token_linear_row_split_weight_gradient(dev, dtype, rows):
     """amp_cache.linear (row-split batched GEMM for the weight gradient) == F.linear, incl. a row count with no divisor."""

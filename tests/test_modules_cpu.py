@@ -36,3 +36,41 @@ def test_dynmask_mso(golden):
 
 def test_matcher_criterion(golden):
     mc.check_matcher_crit(golden("matcher_crit"), CPU)
+
+
+def test_mask_memo_equals_uncached():
+    """Everything memoised on the tagged padding mask (level masks, 2-D position encodings) equals the uncached
+    evaluation on the same mask without the tag; a different valid extent is a different cache entry."""
+    from ocpg_amd.models.position_encoding import PositionEmbeddingSine2D
+    from ocpg_amd.util import misc
+    clips = [torch.randn(2, 3, 40, 56), torch.randn(2, 3, 33, 64)]
+    nt = misc.nested_tensor_from_videos_list(clips, size_divisibility=32)
+    assert misc.mask_key(nt.mask) == ("rect", 64, 64, ((40, 56), (40, 56), (33, 64), (33, 64)))
+    m = nt.mask.flatten(0, 1)
+    m._ocpg_key = nt.mask._ocpg_key
+    plain = m.clone()
+    pe = PositionEmbeddingSine2D(16, normalize=True)
+    for size in ((8, 8), (4, 4), (2, 2)):
+        a, b = misc.resize_mask(m, size), misc.resize_mask(plain, size)
+        assert torch.equal(a, b) and misc.mask_key(a) is not None and misc.mask_key(b) is None
+        assert misc.resize_mask(m, size) is a                    # second call: the cached tensor
+        assert torch.equal(pe(misc.NestedTensor(None, a)), pe(misc.NestedTensor(None, b)))
+    other = misc.nested_tensor_from_videos_list([torch.randn(2, 3, 40, 48), torch.randn(2, 3, 33, 64)], size_divisibility=32)
+    o = other.mask.flatten(0, 1)
+    o._ocpg_key = other.mask._ocpg_key
+    assert not torch.equal(misc.resize_mask(o, (8, 8)), misc.resize_mask(m, (8, 8)))
+
+
+def test_inverse_sigmoid_matches_reference_formula():
+    from ocpg_amd.util.misc import inverse_sigmoid
+    x = torch.cat([torch.rand(1000), torch.tensor([1e-4, 0.5, 1 - 1e-4, 0.3, 0.999])]).requires_grad_(True)
+    ref = torch.log(x.clamp(0, 1).clamp(min=1e-5) / (1 - x.clamp(0, 1)).clamp(min=1e-5))
+    got = inverse_sigmoid(x)
+    assert torch.equal(got, ref)
+    g0, = torch.autograd.grad(ref.sum(), x)
+    g1, = torch.autograd.grad(got.sum(), x)
+    assert torch.allclose(g0, g1, rtol=1e-6, atol=0)
+    ends = torch.tensor([0.0, 1.0, -0.5, 1.5])
+    ref_e = torch.log(ends.clamp(0, 1).clamp(min=1e-5) / (1 - ends.clamp(0, 1)).clamp(min=1e-5))
+    assert (inverse_sigmoid(ends) - ref_e).abs().max() <= 1.5e-3           # saturated ends only (see the docstring)
+    assert (inverse_sigmoid(ends).sigmoid() - ref_e.sigmoid()).abs().max() <= 2e-8
