@@ -300,6 +300,8 @@ def main():
 
     torch.manual_seed(42 + rank)
     torch.backends.cudnn.benchmark = True
+    if os.environ.get("OCPG_BLAS"):          # A/B: 'hipblas' (rocBLAS) | 'hipblaslt'
+        torch.backends.cuda.preferred_blas_library(os.environ["OCPG_BLAS"])
     args = model_args(device, a.backbone, amp=a.dtype != "fp32", roberta=a.text == "roberta")
     model, criterion, _ = build_model(args)
     model.to(device)

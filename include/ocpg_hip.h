@@ -109,6 +109,18 @@ int ocpg_dynmask_fwd_f32(const float* feats, const float* params, const float* r
 int ocpg_im2col3x3_nhwc(const void* x, int N, int H, int W, int C, int stride, int dil, void* cols, int dtype, void* stream);
 int ocpg_col2im3x3_nhwc(const void* dcols, int N, int H, int W, int C, int stride, int dil, void* dx, int dtype, void* stream);
 
+/* Dense GEMM with a per-shape plan cache over hipBLASLt -- replaces the at::mm / at::addmm / at::bmm calls behind
+ * nn.Linear and the 1x1 nn.Conv2d layers on the path (models/deformable_transformer.py:236-257,313-327 FFNs,
+ * models/ops/modules/ms_deform_attn.py:63-66 projections, torchvision Bottleneck.conv1/conv3 via models/backbone.py) and
+ * their gradients; same hipBLASLt kernels, ~1/3 of the host cost per call (the step is launch-bound).
+ * Row-major:  C[M,N] = alpha * op(A) op(B) + beta * C (+ bias[N]);  op(A) = A [M,K] (lda) or A^T with A stored [K,M];
+ * op(B) = B [K,N] (ldb) or B^T with B stored [N,K].  batch > 1: strided batches (element strides).  dtype / out_dtype:
+ * 0 fp32, 1 bf16, 2 fp16 (fp32 accumulation).  One 64-MB workspace is shared: calls must be stream-ordered. */
+int ocpg_gemm(const void* A, const void* B, void* C, const void* bias, int dtype, int out_dtype, int transA, int transB,
+              long long M, long long N, long long K, long long lda, long long ldb, long long ldc, long long batch,
+              long long strideA, long long strideB, long long strideC, float alpha, float beta, void* stream);
+long long ocpg_gemm_plans(void);      /* number of cached plans (diagnostics) */
+
 /* library / build identification: returns e.g. "ocpg_hip gfx950 r1" */
 const char* ocpg_hip_version(void);
 

@@ -13,6 +13,8 @@ LIB = os.path.join(LIBDIR, "libocpg_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-std=c++17", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-function"]
+# gemm.hip plans GEMMs through hipBLASLt (soname libhipblaslt.so.1: inside a torch process the copy torch already loaded)
+LINK = ["-L/opt/rocm/lib", "-lhipblaslt"]
 
 
 def sources():
@@ -25,7 +27,7 @@ def build(force=False, verbose=False):
     deps = srcs + glob.glob(os.path.join(HERE, "*.h")) + glob.glob(os.path.join(HERE, "..", "..", "include", "*.h"))
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in deps):
         return LIB
-    cmd = [HIPCC] + FLAGS + ["-o", LIB] + srcs
+    cmd = [HIPCC] + FLAGS + ["-o", LIB] + srcs + LINK
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -7,6 +7,7 @@ names (conv1, bn1, layerK.i.{conv1,bn1,conv2,bn2,conv3,bn3,downsample.{0,1}}) so
 MI355X notes: frozen BN + residual add + ReLU are ONE hand-written HIP pass (csrc/bn_act.hip) with a cached per-channel
 scale/shift (the reference runs 4 elementwise kernels per BN, plus add, plus ReLU; 104 BNs in ResNet-101).
 """
+import os
 from typing import List
 
 import torch
@@ -15,6 +16,7 @@ from torch import nn
 
 from ..util.misc import NestedTensor, mask_key, resize_mask
 from . import amp_cache
+from .ops.functions import conv_bn_func
 from .ops.functions.bn_act_func import frozen_bn_act
 from .position_encoding import build_position_encoding
 
@@ -62,6 +64,22 @@ class FrozenBatchNorm2d(nn.Module):
         return F.relu(y) if relu else y
 
 
+FUSED_CONV_BN = os.environ.get("OCPG_FUSED_CONV_BN", "1") != "0"     # A/B switch
+
+
+def conv_bn_act(conv, bn, x, skip, relu):
+    """act(bn(conv(x)) (+ skip)).  1x1/stride-1 convs of channels-last GPU maps: one fused autograd node (hipBLASLt GEMM
+    through the plan cache + the frozen-BN HIP kernel in place, ops/functions/conv_bn_func.py); anything else: the two
+    modules in sequence."""
+    if FUSED_CONV_BN and amp_cache.GEMM_1X1 and conv_bn_func.eligible(x, conv):
+        w = amp_cache.lookup(conv.weight)
+        if w.dtype == x.dtype:
+            scale, shift = bn.scale_shift()
+            n, _, h, wd = x.shape
+            return conv_bn_func.conv1x1_bn_act(x, w, scale, shift, skip, relu, amp_cache._split_rows(n * h * wd) if amp_cache.SPLIT_K else 1)
+    return bn(conv(x), skip=skip, relu=relu)
+
+
 class Bottleneck(nn.Module):
     def __init__(self, cin, width, stride, dilation, project):
         super().__init__()
@@ -77,10 +95,10 @@ class Bottleneck(nn.Module):
                                             FrozenBatchNorm2d(width * 4))
 
     def forward(self, x):
-        y = self.bn1(self.conv1(x), relu=True)
+        y = conv_bn_act(self.conv1, self.bn1, x, None, True)
         y = self.bn2(self.conv2(y), relu=True)
-        skip = x if self.downsample is None else self.downsample[1](self.downsample[0](x))
-        return self.bn3(self.conv3(y), skip=skip, relu=True)
+        skip = x if self.downsample is None else conv_bn_act(self.downsample[0], self.downsample[1], x, None, False)
+        return conv_bn_act(self.conv3, self.bn3, y, skip, True)
 
 
 class ResNetBody(nn.Module):

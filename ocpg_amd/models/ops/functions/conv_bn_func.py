@@ -1,0 +1,91 @@
+"""1x1 convolution + frozen-BN affine (+ residual) (+ ReLU) of a channels-last map as ONE autograd node.
+
+Forward: ocpg_gemm (hipBLASLt, cached plan, straight on the NHWC buffers: no view ops) -> ocpg_bn_act_fwd in place.
+Backward: ocpg_bn_act_bwd -> input gradient GEMM + weight gradient GEMM (row-split, amp_cache.weight_grad's rule).
+Replaces torchvision Bottleneck's conv1+bn1+relu, conv3+bn3(+identity)+relu and downsample conv+bn as the reference
+runs them (models/backbone.py:46-56 FrozenBatchNorm2d + nn.Conv2d).  The step is launch-bound on the host: one Python
+autograd node and 2 (forward) / 3-4 (backward) C calls replace two nodes and ~10 tensor-view ops per layer.
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from ...._lib import check, lib
+
+_DT = {torch.float32: 0, torch.bfloat16: 1}
+_CL = torch.channels_last
+
+
+def eligible(x, conv):
+    return (x.is_cuda and x.dim() == 4 and x.dtype in _DT and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)
+            and conv.groups == 1 and conv.bias is None and x.is_contiguous(memory_format=_CL))
+
+
+class Conv1x1BNAct(Function):
+    @staticmethod
+    def forward(ctx, x, w, scale, shift, skip, relu, splits):
+        n, c, h, wd = x.shape
+        co = w.shape[0]
+        m = n * h * wd
+        dt = _DT[x.dtype]
+        L = lib()
+        st = torch.cuda.current_stream().cuda_stream
+        y = torch.empty((n, co, h, wd), dtype=x.dtype, device=x.device, memory_format=_CL)
+        # y[m, co] = x[m, c] w[co, c]^T
+        rc = L.ocpg_gemm(x.data_ptr(), w.data_ptr(), y.data_ptr(), None, dt, dt, 0, 1, m, co, c, c, c, co, 1, 0, 0, 0, 1.0, 0.0, st)
+        if rc:
+            check(rc, "ocpg_gemm")
+        if skip is not None and (skip.dtype != x.dtype or not skip.is_contiguous(memory_format=_CL)):
+            skip = skip.to(x.dtype).contiguous(memory_format=_CL)
+        rc = L.ocpg_bn_act_fwd(y.data_ptr(), scale.data_ptr(), shift.data_ptr(), None if skip is None else skip.data_ptr(), y.data_ptr(),
+                               m, co, 1, int(relu), dt, st)
+        if rc:
+            check(rc, "ocpg_bn_act_fwd")
+        ctx.save_for_backward(x, w, y, scale)
+        ctx.meta = (bool(relu), skip is not None, splits)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, w, y, scale = ctx.saved_tensors
+        relu, has_skip, splits = ctx.meta
+        n, c, h, wd = x.shape
+        co = w.shape[0]
+        m = n * h * wd
+        dt = _DT[x.dtype]
+        L = lib()
+        st = torch.cuda.current_stream().cuda_stream
+        if gy.dtype != y.dtype or not gy.is_contiguous(memory_format=_CL):
+            gy = gy.to(y.dtype).contiguous(memory_format=_CL)
+        need_x, need_w, need_skip = ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_skip and ctx.needs_input_grad[4]
+        gz = torch.empty_like(y)
+        gskip = torch.empty_like(y) if need_skip else None
+        rc = L.ocpg_bn_act_bwd(gy.data_ptr(), y.data_ptr(), scale.data_ptr(), gz.data_ptr(), None if gskip is None else gskip.data_ptr(),
+                               m, co, 1, int(relu), dt, st)
+        if rc:
+            check(rc, "ocpg_bn_act_bwd")
+        gx = gw = None
+        if need_x:      # gx[m, c] = gz[m, co] w[co, c]
+            gx = torch.empty((n, c, h, wd), dtype=x.dtype, device=x.device, memory_format=_CL)
+            rc = L.ocpg_gemm(gz.data_ptr(), w.data_ptr(), gx.data_ptr(), None, dt, dt, 0, 0, m, c, co, co, c, c, 1, 0, 0, 0, 1.0, 0.0, st)
+            if rc:
+                check(rc, "ocpg_gemm")
+        if need_w:      # gw[co, c] = gz[m, co]^T x[m, c], rows split into `splits` chunks (one strided-batched GEMM + a sum)
+            if splits > 1 and m % splits == 0:
+                r = m // splits
+                part = torch.empty((splits, co, c), dtype=x.dtype, device=x.device)
+                rc = L.ocpg_gemm(gz.data_ptr(), x.data_ptr(), part.data_ptr(), None, dt, dt, 1, 0, co, c, r, co, c, c, splits, r * co, r * c,
+                                 co * c, 1.0, 0.0, st)
+                gw = part.sum(0)
+            else:
+                gw = torch.empty((co, c), dtype=x.dtype, device=x.device)
+                rc = L.ocpg_gemm(gz.data_ptr(), x.data_ptr(), gw.data_ptr(), None, dt, dt, 1, 0, co, c, m, co, c, c, 1, 0, 0, 0, 1.0, 0.0, st)
+            if rc:
+                check(rc, "ocpg_gemm")
+            gw = gw.view(w.shape)
+        return gx, gw, None, None, gskip, None, None
+
+
+def conv1x1_bn_act(x, w, scale, shift, skip, relu, splits):
+    return Conv1x1BNAct.apply(x, w, scale, shift, skip, relu, splits)
