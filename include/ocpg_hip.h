@@ -121,6 +121,25 @@ int ocpg_gemm(const void* A, const void* B, void* C, const void* bias, int dtype
               long long strideA, long long strideB, long long strideC, float alpha, float beta, void* stream);
 long long ocpg_gemm_plans(void);      /* number of cached plans (diagnostics) */
 
+/* Mask-criterion losses, all decoder layers per call (fp32; replace the elementwise/reduction chains of
+ * models/segmentation.py:203-211,253-315 as called from models/criterion.py:141-178).
+ *
+ * Level-set loss: x [Lr,N,h,w] logits, feats [N,CF,h,w] (first C channels used, C <= 16), box [N,h,w] in {0,1}.
+ *   fwd: sums [Lr,N,7+2C] and coef [Lr,N,8+2C] are scratch the backward re-reads; loss [Lr].
+ *   bwd: gloss [Lr] upstream gradient -> gx [Lr,N,h,w], gfeat [N,CF,h,w] (may be NULL), both fully written. */
+int ocpg_levelset_fwd_f32(const float* x, const float* feats, const float* box, int Lr, int N, int C, int CF, int h, int w, float* sums,
+                          float* coef, float* loss, void* stream);
+int ocpg_levelset_bwd_f32(const float* x, const float* feats, const float* box, const float* coef, const float* gloss, int Lr, int N,
+                          int C, int CF, int h, int w, float* gx, float* gfeat, void* stream);
+/* Box-projection loss with mean term: x [Lr,B,T,H,W] logits; targets tcmax/tcmean [B,T,W] (region.amax / weak.mean over H),
+ * trmax/trmean [B,T,H] (over W).  fwd: colstat [Lr*B*T,3,W], rowstat [Lr*B*T,3,H], IU [Lr,B,4,2] scratch kept for the
+ * backward; loss [Lr].  bwd: Gc [Lr*B*T,2,W], Gr [Lr*B*T,2,H] scratch; gx [Lr,B,T,H,W] fully written. */
+int ocpg_proj_fwd_f32(const float* x, const float* tcmax, const float* trmax, const float* tcmean, const float* trmean, int Lr, int B,
+                      int T, int H, int W, float* colstat, float* rowstat, float* IU, float* loss, void* stream);
+int ocpg_proj_bwd_f32(const float* x, const float* tcmax, const float* trmax, const float* tcmean, const float* trmean,
+                      const float* colstat, const float* rowstat, const float* IU, const float* gloss, int Lr, int B, int T, int H, int W,
+                      float* Gc, float* Gr, float* gx, void* stream);
+
 /* library / build identification: returns e.g. "ocpg_hip gfx950 r1" */
 const char* ocpg_hip_version(void);
 

@@ -27,6 +27,10 @@ SIGNATURES = {
     "ocpg_dynmask_fwd_f32": [_vp, _vp, _vp] + [_int] * 6 + [_vp, _vp, _vp],
     "ocpg_gemm": [_vp, _vp, _vp, _vp] + [_int] * 4 + [ctypes.c_longlong] * 10 + [ctypes.c_float, ctypes.c_float, _vp],
     "ocpg_gemm_plans": [],
+    "ocpg_levelset_fwd_f32": [_vp] * 3 + [_int] * 6 + [_vp] * 4,
+    "ocpg_levelset_bwd_f32": [_vp] * 5 + [_int] * 6 + [_vp] * 3,
+    "ocpg_proj_fwd_f32": [_vp] * 5 + [_int] * 5 + [_vp] * 5,
+    "ocpg_proj_bwd_f32": [_vp] * 9 + [_int] * 5 + [_vp] * 4,
     "ocpg_im2col3x3_nhwc": [_vp] + [_int] * 6 + [_vp, _int, _vp],
     "ocpg_col2im3x3_nhwc": [_vp] + [_int] * 6 + [_vp, _int, _vp],
     "ocpg_win_attn_fwd": [_vp, _vp, _vp, ctypes.c_float] + [_int] * 5 + [_vp, _vp, _int, _vp],

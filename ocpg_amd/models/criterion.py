@@ -20,7 +20,10 @@ from torch import nn
 from ..util import box_ops
 from ..util.misc import get_world_size, is_dist_avail_and_initialized, nested_tensor_from_tensor_list
 from .matcher import _assert_well_formed, _pairwise_giou_1
+from .ops.functions import mask_loss_func
 from .segmentation import generate_box_region_mask
+
+HIP_MASK_LOSSES = True      # A/B switch: fused HIP level-set / projection losses on the GPU
 
 
 def _pad_stack(targets, key):
@@ -155,11 +158,19 @@ class SetCriterion(nn.Module):
         scaled = F.interpolate(pm.flatten(0, 1), lst_hw, mode="bilinear", align_corners=True).view(lr, b * nf, *lst_hw)
         region_scaled = F.interpolate(region, lst_hw, mode="nearest").flatten(0, 1)
         feats = src_lst.flatten(0, 1)[:, :-1]
-        ls = levelset(scaled, feats, region_scaled)
-        ls_low = levelset(pml.flatten(1, 2), feats, region_scaled)
+        if pm.is_cuda and HIP_MASK_LOSSES and feats.shape[1] <= 16:
+            # fused HIP kernels (csrc/levelset.hip, csrc/proj.hip): 2-3 launches per loss instead of ~30-60 (+ twice that backward)
+            full_feats = src_lst.flatten(0, 1)                     # the kernel skips the dropped last channel itself
+            ls = mask_loss_func.levelset_loss(scaled, full_feats, region_scaled, feats.shape[1])
+            ls_low = mask_loss_func.levelset_loss(pml.flatten(1, 2), full_feats, region_scaled, feats.shape[1])
+            pj, pj_low = mask_loss_func.proj_loss(pm, region, weak_full), mask_loss_func.proj_loss(pml, region_low, weak_low)
+        else:
+            ls = levelset(scaled, feats, region_scaled)
+            ls_low = levelset(pml.flatten(1, 2), feats, region_scaled)
+            pj, pj_low = proj(pm, region, weak_full), proj(pml, region_low, weak_low)
         out = {
-            "loss_proj": proj(pm, region, weak_full), "loss_mask": (1 - warm) * loss_mask, "loss_lst": warm * ls,
-            "loss_proj_low": proj(pml, region_low, weak_low), "loss_mask_low": (1 - warm) * loss_mask_low, "loss_lst_low": warm * ls_low,
+            "loss_proj": pj, "loss_mask": (1 - warm) * loss_mask, "loss_lst": warm * ls,
+            "loss_proj_low": pj_low, "loss_mask_low": (1 - warm) * loss_mask_low, "loss_lst_low": warm * ls_low,
         }
         return out, (pm[0].sigmoid(), gt_full, weak_full)
 

@@ -99,6 +99,56 @@ def test_pointwise_conv_as_gemm(dev, dtype, bias):
         assert a.shape == b_.shape and (a - b_).abs().max().item() <= tol * b_.abs().max().item() + 1e-6
 
 
+@pytest.mark.parametrize("case", ["regular", "degenerate"])
+def test_hip_mask_losses_equal_torch_formulas(dev, case):
+    """csrc/levelset.hip + csrc/proj.hip (all layers per launch) against the criterion's own tensor-op restatement of
+    segmentation.py:203-315 on the same inputs: the six mask losses of 3 stacked layers and the gradients w.r.t. both mask
+    resolutions and the level-set features.  'degenerate': saturated logits (ties in the row/column maxima, zero
+    foreground mass -> the 1e-5 clamps are active), a frame whose box region is empty, odd sizes."""
+    import synth
+    from ocpg_amd.models import build_model, criterion as crit_mod
+    import cases
+    torch.manual_seed(0)
+    args = cases.default_args(device=str(dev), **cases.TINY)
+    _, crit, _ = build_model(args)
+    crit.to(dev)
+    lr, b, t = 3, 2, 3
+    H, W = (64, 96) if case == "regular" else (32, 64)
+    targets = synth.synthetic_targets(b, t, H, W, dev)
+    targets[0]["weights"] = torch.rand(t, H, W, device=dev) * targets[0]["masks"]
+    if case == "degenerate":
+        targets[1]["boxes"] = torch.tensor([[0.375, 0.375, 0.25, 0.25], [0.5, 0.5, 0.0, 0.0], [0.2, 0.7, 0.3, 0.5]], device=dev)
+    gen = torch.Generator(device=dev).manual_seed(7)
+    pm = torch.randn(lr, b, t, H, W, device=dev, generator=gen) * 3
+    pml = torch.randn(lr, b, t, H // 2, W // 2, device=dev, generator=gen) * 3
+    if case == "degenerate":
+        pm[0, 0] = 40.0          # saturated: every pixel ties for the maximum, p (1 - p) == 0
+        pm[1, 1, 0] = -40.0      # zero foreground mass in a frame
+        pml[0, 1] = -40.0
+        pml[2, 0, 1] = 40.0
+    ls = torch.randn(b, t, 12, H // 2, W // 2, device=dev, generator=gen)
+    warm = torch.tensor([0.3, 0.6, 1.0], device=dev)
+    nb = torch.tensor(float(b * t), device=dev)
+    res = []
+    for on in (True, False):
+        crit_mod.HIP_MASK_LOSSES = on
+        try:
+            leaves = [x.clone().requires_grad_(True) for x in (pm, pml, ls)]
+            d, _ = crit._masks_stacked(leaves[0], leaves[1], leaves[2], targets, nb, warm)
+            wts = {k: 1.0 + 0.1 * i for i, k in enumerate(sorted(d))}
+            total = sum((d[k] * torch.arange(1, lr + 1, device=dev)).sum() * wts[k] for k in d)
+            grads = torch.autograd.grad(total, leaves)
+            res.append(({k: v.detach() for k, v in d.items()}, grads))
+        finally:
+            crit_mod.HIP_MASK_LOSSES = True
+    (d1, g1), (d0, g0) = res
+    for k in d0:
+        assert torch.allclose(d1[k], d0[k], rtol=2e-4, atol=1e-6), (k, d1[k], d0[k])
+    for a, b_, name in zip(g1, g0, ("pm", "pml", "ls_features")):
+        err = (a - b_).abs().max().item()
+        assert err <= 2e-4 * b_.abs().max().item() + 1e-9, (name, err, b_.abs().max().item())
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("project", [False, True])
 def test_bottleneck_fused_conv_bn_act(dev, dtype, project):
