@@ -140,6 +140,18 @@ int ocpg_proj_bwd_f32(const float* x, const float* tcmax, const float* trmax, co
                       const float* colstat, const float* rowstat, const float* IU, const float* gloss, int Lr, int B, int T, int H, int W,
                       float* Gc, float* Gr, float* gx, void* stream);
 
+/* Matching cost [Lr,B,Q] of every query against the clip's single target -- replaces the cost construction of
+ * HungarianMatcher.forward (models/matcher.py:74-160) for all decoder layers: wc * focal-class (mean over valid frames) +
+ * wb * L1 + wg * (-GIoU) (means over frames) + wm * sigmoid-focal + wd * (-dice) (over the clip's pixels).
+ * logits [Lr,B,T,Q,K], boxes [Lr,B,T,Q,4] cxcywh, contiguous; masks: logits with element strides (sl,sb,st,sq) for
+ * (layer, clip, frame, query) and a contiguous [h,w] tail; gt [B,T,h,w]; tboxes [B,T,4]; valid [B,T] (float);
+ * labels [B,T] int64 or NULL (class 0).  sums [Lr,B,Q,4] scratch.  bad: optional int32 counter, +1 per (layer,clip,query)
+ * with a malformed box. */
+int ocpg_matcher_cost_f32(const float* logits, const float* boxes, const float* masks, long long sl, long long sb, long long st,
+                          long long sq, const float* gt, const float* tboxes, const float* valid, const long long* labels, int Lr,
+                          int B, int T, int Q, int K, int h, int w, float wc, float wb, float wg, float wm, float wd, float* sums,
+                          float* cost, int* bad, void* stream);
+
 /* library / build identification: returns e.g. "ocpg_hip gfx950 r1" */
 const char* ocpg_hip_version(void);
 

@@ -31,6 +31,7 @@ SIGNATURES = {
     "ocpg_levelset_bwd_f32": [_vp] * 5 + [_int] * 6 + [_vp] * 3,
     "ocpg_proj_fwd_f32": [_vp] * 5 + [_int] * 5 + [_vp] * 5,
     "ocpg_proj_bwd_f32": [_vp] * 9 + [_int] * 5 + [_vp] * 4,
+    "ocpg_matcher_cost_f32": [_vp] * 3 + [ctypes.c_longlong] * 4 + [_vp] * 4 + [_int] * 7 + [ctypes.c_float] * 5 + [_vp] * 4,
     "ocpg_im2col3x3_nhwc": [_vp] + [_int] * 6 + [_vp, _int, _vp],
     "ocpg_col2im3x3_nhwc": [_vp] + [_int] * 6 + [_vp, _int, _vp],
     "ocpg_win_attn_fwd": [_vp, _vp, _vp, ctypes.c_float] + [_int] * 5 + [_vp, _vp, _int, _vp],

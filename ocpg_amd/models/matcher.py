@@ -32,6 +32,7 @@ def _pairwise_giou_1(boxes, tgt):
     return iou - ((hull - union) + 1e-6) / (hull + 1e-6)
 
 
+HIP_MATCHER = True      # A/B switch: one-launch HIP cost matrix on the GPU
 _BOX_ERRORS = {}      # device -> 0-dim int32 counter of malformed-box events (GPU path: recorded, never trapped)
 
 
@@ -86,6 +87,8 @@ class HungarianMatcher(nn.Module):
             assert gt.size(2) * s == im_h and gt.size(3) * s == im_w
 
             valid = torch.stack([t["valid"] for t in targets]).to(logits.dtype)                  # [B, T]
+            if masks.is_cuda and HIP_MATCHER:
+                return self._cost_matrix_hip(logits, boxes, masks, gt, valid, targets)
             prob = logits.sigmoid()                                                              # [Lr, B, T, q, K]
             alpha, gamma = 0.25, 2.0
             neg = (1 - alpha) * (prob ** gamma) * (-(1 - prob + 1e-8).log())
@@ -114,6 +117,29 @@ class HungarianMatcher(nn.Module):
             cost_dice = -((2 * (p * g).sum(3) + 1) / (p.sum(-1) + g.sum(-1) + 1))
             return (self.cost_class * cost_class + self.cost_bbox * cost_bbox + self.cost_giou * cost_giou
                     + self.cost_mask * cost_mask + self.cost_dice * cost_dice)
+
+    def _cost_matrix_hip(self, logits, boxes, masks, gt, valid, targets):
+        """One launch of csrc/matcher.hip for all layers, clips and queries."""
+        from .._lib import check, lib
+        lr, bs, nf, nq, h, w = masks.shape
+        if masks.stride(-1) != 1 or masks.stride(-2) != w:
+            masks = masks.contiguous()
+        logits, boxes, gt = logits.contiguous(), boxes.contiguous(), gt.contiguous()
+        tb = torch.stack([t["boxes"] for t in targets]).to(boxes.dtype).contiguous()
+        labels = None if self.num_classes == 1 else torch.stack([t["labels"] for t in targets]).to(torch.int64).contiguous()
+        flag = _BOX_ERRORS.get(masks.device)
+        if flag is None and not torch.cuda.is_current_stream_capturing():
+            flag = _BOX_ERRORS[masks.device] = torch.zeros((), dtype=torch.int32, device=masks.device)
+        cost = torch.empty((lr, bs, nq), dtype=torch.float32, device=masks.device)
+        sums = torch.empty((lr, bs, nq, 4), dtype=torch.float32, device=masks.device)
+        sl, sb, st, sq = masks.stride()[:4]
+        check(lib().ocpg_matcher_cost_f32(logits.data_ptr(), boxes.data_ptr(), masks.data_ptr(), sl, sb, st, sq, gt.data_ptr(), tb.data_ptr(),
+                                          valid.contiguous().data_ptr(), None if labels is None else labels.data_ptr(), lr, bs, nf, nq,
+                                          logits.shape[-1], h, w, float(self.cost_class), float(self.cost_bbox), float(self.cost_giou),
+                                          float(self.cost_mask), float(self.cost_dice), sums.data_ptr(), cost.data_ptr(),
+                                          None if flag is None else flag.data_ptr(), torch.cuda.current_stream().cuda_stream),
+              "ocpg_matcher_cost_f32")
+        return cost
 
     @torch.no_grad()
     def cost_matrix(self, outputs, targets):

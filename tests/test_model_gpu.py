@@ -99,6 +99,41 @@ def test_pointwise_conv_as_gemm(dev, dtype, bias):
         assert a.shape == b_.shape and (a - b_).abs().max().item() <= tol * b_.abs().max().item() + 1e-6
 
 
+@pytest.mark.parametrize("num_classes", [1, 7])
+def test_hip_matcher_cost_equals_torch_formulas(dev, num_classes):
+    """csrc/matcher.hip (one launch for all layers / clips / queries, strided mask view) against the matcher's tensor-op
+    cost matrix: values to fp32 rounding, argmin identical; invalid frames, multi-class labels, a malformed box counted."""
+    import synth
+    from ocpg_amd.models import matcher as mm
+    torch.manual_seed(0)
+    m = mm.HungarianMatcher(cost_class=2, cost_bbox=5, cost_giou=2, cost_mask=2, cost_dice=5, num_classes=num_classes).to(dev)
+    lr, b, t, q, H, W = 3, 2, 3, 5, 64, 96
+    targets = synth.synthetic_targets(b, t, H, W, dev)
+    targets[1]["valid"] = torch.tensor([1, 0, 1], device=dev)
+    targets[1]["labels"] = torch.tensor([3, 0, 5], device=dev)
+    gen = torch.Generator(device=dev).manual_seed(11)
+    logits = torch.randn(lr, b, t, q, num_classes, device=dev, generator=gen)
+    boxes = torch.rand(lr, b, t, q, 4, device=dev, generator=gen) * 0.4 + 0.2
+    base = torch.randn(b, t, lr, q, H // 2, W // 2, device=dev, generator=gen) * 2        # the model's [b,t,l,q,...] layout
+    masks = base.permute(2, 0, 1, 3, 4, 5)                                               # [l,b,t,q,h,w] strided view
+    res = []
+    for on in (True, False):
+        mm.HIP_MATCHER = on
+        try:
+            res.append(m.cost_matrix_stacked(logits, boxes, masks, targets))
+        finally:
+            mm.HIP_MATCHER = True
+    assert torch.allclose(res[0], res[1], rtol=2e-5, atol=2e-6), (res[0] - res[1]).abs().max()
+    assert torch.equal(res[0].argmin(2), res[1].argmin(2))
+    flag = mm._BOX_ERRORS[torch.device(dev) if not isinstance(dev, torch.device) else dev]
+    before = int(flag.item())
+    bad = boxes.clone()
+    bad[0, 0, 0, 0, 2] = -0.1                     # negative width -> x1 < x0
+    m.cost_matrix_stacked(logits, bad, masks, targets)
+    assert int(flag.item()) > before
+    flag.zero_()
+
+
 @pytest.mark.parametrize("case", ["regular", "degenerate"])
 def test_hip_mask_losses_equal_torch_formulas(dev, case):
     """csrc/levelset.hip + csrc/proj.hip (all layers per launch) against the criterion's own tensor-op restatement of
