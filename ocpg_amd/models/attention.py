@@ -27,11 +27,26 @@ class MultiheadAttention(nn.Module):
         Lk = key.shape[0]
         H, hd = self.num_heads, C // self.num_heads
         w, b = lookup(self.in_proj_weight), lookup(self.in_proj_bias)
-        q = F.linear(query, w[:C], b[:C]).view(Lq, B, H, hd).permute(1, 2, 0, 3)
-        k = F.linear(key, w[C:2 * C], b[C:2 * C]).view(Lk, B, H, hd).permute(1, 2, 0, 3)
-        v = F.linear(value, w[2 * C:], b[2 * C:]).view(Lk, B, H, hd).permute(1, 2, 0, 3)
+        # split the packed projection ONCE (backward: one cat per parameter, not three zero-fill + copy + add chains)
+        if query is key:        # decoder self-attention: q and k from the same input -> one GEMM
+            wqk, wv = w.split([2 * C, C])
+            bqk, bv = b.split([2 * C, C])
+            qk = F.linear(query, wqk, bqk).view(Lq, B, 2, H, hd)
+            q, k = qk[:, :, 0].permute(1, 2, 0, 3), qk[:, :, 1].permute(1, 2, 0, 3)
+        else:
+            wq, wk, wv = w.chunk(3)
+            bq, bk, bv = b.chunk(3)
+            q = F.linear(query, wq, bq).view(Lq, B, H, hd).permute(1, 2, 0, 3)
+            k = F.linear(key, wk, bk).view(Lk, B, H, hd).permute(1, 2, 0, 3)
+        v = F.linear(value, wv, bv).view(Lk, B, H, hd).permute(1, 2, 0, 3)
         mask = None
         if key_padding_mask is not None:
-            mask = torch.zeros((B, 1, 1, Lk), dtype=q.dtype, device=q.device).masked_fill(key_padding_mask[:, None, None, :], float("-inf"))
+            cache = key_padding_mask.__dict__.setdefault("_ocpg_additive", {}) if hasattr(key_padding_mask, "__dict__") else {}
+            hit = cache.get(q.dtype)
+            if hit is None or hit[0] != key_padding_mask._version:
+                # the same padding mask serves every level / layer of a forward: build its additive form once per content version
+                hit = cache[q.dtype] = (key_padding_mask._version, torch.zeros((B, 1, 1, Lk), dtype=q.dtype, device=q.device).masked_fill(
+                    key_padding_mask[:, None, None, :], float("-inf")))
+            mask = hit[1]
         o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=self.dropout if self.training else 0.0)
         return self.out_proj(o.permute(2, 0, 1, 3).reshape(Lq, B, C))

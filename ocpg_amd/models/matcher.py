@@ -17,18 +17,14 @@ from ..util.misc import nested_tensor_from_tensor_list
 def _pairwise_giou_1(boxes, tgt):
     """GIoU of boxes [..., 4] against one target box per leading index, tgt [..., 4] (xyxy), with the reference's
     +1e-6 smoothing (util/box_ops.py:45-85)."""
-    area_a = (boxes[..., 2] - boxes[..., 0]) * (boxes[..., 3] - boxes[..., 1])
-    area_b = (tgt[..., 2] - tgt[..., 0]) * (tgt[..., 3] - tgt[..., 1])
-    lt = torch.max(boxes[..., :2], tgt[..., :2])
-    rb = torch.min(boxes[..., 2:], tgt[..., 2:])
-    wh = (rb - lt).clamp(min=0)
-    inter = wh[..., 0] * wh[..., 1]
+    ax0, ay0, ax1, ay1 = boxes.unbind(-1)          # one unbind (backward: one stack) instead of 12 select/slice nodes
+    bx0, by0, bx1, by1 = tgt.unbind(-1)
+    area_a = (ax1 - ax0) * (ay1 - ay0)
+    area_b = (bx1 - bx0) * (by1 - by0)
+    inter = (torch.min(ax1, bx1) - torch.max(ax0, bx0)).clamp(min=0) * (torch.min(ay1, by1) - torch.max(ay0, by0)).clamp(min=0)
     union = area_a + area_b - inter
     iou = (inter + 1e-6) / (union + 1e-6)
-    lt = torch.min(boxes[..., :2], tgt[..., :2])
-    rb = torch.max(boxes[..., 2:], tgt[..., 2:])
-    wh = (rb - lt).clamp(min=0)
-    hull = wh[..., 0] * wh[..., 1]
+    hull = (torch.max(ax1, bx1) - torch.min(ax0, bx0)).clamp(min=0) * (torch.max(ay1, by1) - torch.min(ay0, by0)).clamp(min=0)
     return iou - ((hull - union) + 1e-6) / (hull + 1e-6)
 
 
