@@ -287,10 +287,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    # OCPG_REHEARSE_ONE_GPU=1: rehearsal of the N>1 code path on a one-GPU box (all ranks on cuda:0, gloo instead of RCCL,
+    # which refuses two ranks per device); never a measurement
+    rehearse = os.environ.get("OCPG_REHEARSE_ONE_GPU") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
+        if rehearse:
+            dist.init_process_group(backend="gloo", init_method="env://")
+        else:
+            dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
 
     from ocpg_amd import _lib
@@ -343,8 +351,11 @@ def main():
     if step is None:
         ddp_model = model
         if world > 1:
+            # broadcast_buffers=False: the only buffers are the frozen BN statistics (identical on every rank, never
+            # updated); re-broadcasting them every step would also invalidate FrozenBatchNorm2d's cached scale/shift
             ddp_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], gradient_as_bucket_view=True,
-                                                                  bucket_cap_mb=64, find_unused_parameters=False)
+                                                                  bucket_cap_mb=64, find_unused_parameters=False,
+                                                                  broadcast_buffers=False)
         step = EagerStep(model, ddp_model, criterion, optimizer, make_samples, text, targets, args, amp_dtype)
 
     def sync():

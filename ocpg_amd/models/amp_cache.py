@@ -30,6 +30,7 @@ class FusedCast(torch.autograd.Function):
         outs = [torch.empty_like(p, dtype=dtype) for p in params]
         torch._foreach_copy_(outs, list(params))
         ctx.src_dtype = params[0].dtype
+        ctx.src_strides = [p.stride() for p in params]
         return tuple(outs)
 
     @staticmethod
@@ -37,7 +38,9 @@ class FusedCast(torch.autograd.Function):
         idx = [i for i, g in enumerate(grads) if g is not None and ctx.needs_input_grad[i + 1]]
         res = [None] * len(grads)
         if idx:
-            outs = [torch.empty_like(grads[i], dtype=ctx.src_dtype) for i in idx]
+            # gradients take the PARAMETER's strides (DDP's gradient-as-bucket-view layout contract: a channels-last
+            # 1x1 weight [Co,Ci,1,1] and its dense gradient share the memory order but not the nominal strides)
+            outs = [torch.empty_strided(grads[i].shape, ctx.src_strides[i], dtype=ctx.src_dtype, device=grads[i].device) for i in idx]
             torch._foreach_copy_(outs, [grads[i] for i in idx])
             for i, o in zip(idx, outs):
                 res[i] = o
