@@ -18,7 +18,33 @@ from torch import nn
 from ..util.misc import inverse_sigmoid, mask_key, memo
 from . import amp_cache
 from .attention import MultiheadAttention
+from .ops.functions import fused_ln_func
 from .ops.modules import MSDeformAttn
+
+FUSED_GLUE = True       # A/B switch: fused dropout+add+LayerNorm and bias+ReLU+dropout kernels (csrc/fused_ln.hip)
+
+
+def _drop_add_norm(x, res, drop, norm):
+    """norm(res + drop(x)): one fused HIP pass each way on the GPU (LayerNorm over <= 2048 channels, fp32 residual stream)."""
+    if FUSED_GLUE and isinstance(norm, nn.LayerNorm) and norm.elementwise_affine and fused_ln_func.supported(x, res, x.shape[-1]):
+        return fused_ln_func.dropout_add_layer_norm(x, res, norm, drop.p if drop.training else 0.0)
+    return norm(res + drop(x))
+
+
+def _ffn_hidden(src, linear1, activation, drop):
+    """drop(activation(linear1(src))): GEMM + one fused bias/ReLU/dropout pass on the GPU (ReLU FFNs)."""
+    if FUSED_GLUE and activation is F.relu and src.is_cuda and linear1.bias is not None:
+        w, b = amp_cache.lookup(linear1.weight), amp_cache.lookup(linear1.bias)
+        x = src
+        if torch.is_autocast_enabled("cuda"):
+            dt = torch.get_autocast_dtype("cuda")
+            x, w, b = x.to(dt), w.to(dt), b.to(dt)
+        if x.dtype == w.dtype and x.dtype in (torch.float32, torch.bfloat16) and w.shape[0] % 4 == 0:
+            x2 = x.reshape(-1, x.shape[-1])
+            splits = amp_cache._split_rows(x2.shape[0]) if amp_cache.SPLIT_K else 1
+            h = fused_ln_func.LinearBiasReluDropout.apply(x2, w, b, drop.p if drop.training else 0.0, None, splits)
+            return h.view(*x.shape[:-1], w.shape[0])
+    return drop(activation(linear1(src)))
 
 
 def _clones(module, n):
@@ -52,9 +78,9 @@ class DeformableTransformerEncoderLayer(nn.Module):
         with torch.autocast(device_type=src.device.type, enabled=False):
             q = src.float() if pos is None else src.float() + pos.float()
             attn = self.self_attn(q, reference_points, src.float(), spatial_shapes, level_start_index, padding_mask)[0]
-        src = self.norm1(src + self.dropout1(attn))
-        ffn = self.linear2(self.dropout2(self.activation(self.linear1(src))))
-        return self.norm2(src + self.dropout3(ffn))
+        src = _drop_add_norm(attn, src, self.dropout1, self.norm1)
+        ffn = self.linear2(_ffn_hidden(src, self.linear1, self.activation, self.dropout2))
+        return _drop_add_norm(ffn, src, self.dropout3, self.norm2)
 
 
 class DeformableTransformerEncoder(nn.Module):
@@ -107,13 +133,13 @@ class DeformableTransformerDecoderLayer(nn.Module):
     def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index, src_padding_mask=None):
         qk = tgt if query_pos is None else tgt + query_pos
         sa = self.self_attn(qk.transpose(0, 1), qk.transpose(0, 1), tgt.transpose(0, 1)).transpose(0, 1)
-        tgt = self.norm2(tgt + self.dropout2(sa))
+        tgt = _drop_add_norm(sa, tgt, self.dropout2, self.norm2)
         with torch.autocast(device_type=tgt.device.type, enabled=False):
             q = tgt.float() if query_pos is None else tgt.float() + query_pos.float()
             ca, loc, weights = self.cross_attn(q, reference_points, src.float(), src_spatial_shapes, level_start_index, src_padding_mask)
-        tgt = self.norm1(tgt + self.dropout1(ca))
-        ffn = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
-        return self.norm3(tgt + self.dropout4(ffn)), loc, weights
+        tgt = _drop_add_norm(ca, tgt, self.dropout1, self.norm1)
+        ffn = self.linear2(_ffn_hidden(tgt, self.linear1, self.activation, self.dropout3))
+        return _drop_add_norm(ffn, tgt, self.dropout4, self.norm3), loc, weights
 
 
 class DeformableTransformerDecoder(nn.Module):

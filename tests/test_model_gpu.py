@@ -99,6 +99,71 @@ def test_pointwise_conv_as_gemm(dev, dtype, bias):
         assert a.shape == b_.shape and (a - b_).abs().max().item() <= tol * b_.abs().max().item() + 1e-6
 
 
+def _probe_keep_mask(rows, cols, p, rng, dev):
+    """The keep/scale pattern csrc/fused_ln.hip generates for (seed, offset) on a [rows, cols] tensor (1/(1-p) or 0)."""
+    from ocpg_amd.models.ops.functions import fused_ln_func as f
+    ones = torch.ones(rows, 1, device=dev)
+    w = torch.ones(cols, 1, device=dev)
+    return f.LinearBiasReluDropout.apply(ones, w, torch.zeros(cols, device=dev), p, rng, 1)
+
+
+@pytest.mark.parametrize("xdtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,c,p", [(1023, 256, 0.0), (37, 1024, 0.0), (5, 20, 0.0), (777, 256, 0.1), (64, 2048, 0.3)])
+def test_fused_dropout_add_layernorm(dev, xdtype, rows, c, p):
+    """LayerNorm(res + dropout(x)) in one pass each way == the three-op formulation with the SAME mask (recovered from
+    the generator through a probe call), outputs and all four gradients; p = 0 is the parity configuration."""
+    from ocpg_amd.models.ops.functions import fused_ln_func as f
+    torch.manual_seed(0)
+    norm = torch.nn.LayerNorm(c).to(dev)
+    norm.weight.data.uniform_(0.5, 1.5), norm.bias.data.normal_(0, 0.2)
+    x = torch.randn(3, rows, c, device=dev).to(xdtype)
+    res = torch.randn(3, rows, c, device=dev)
+    go = torch.randn(3, rows, c, device=dev)
+    rng = (1234567, 42)
+    keep = _probe_keep_mask(3 * rows, c, p, rng, dev).view(3, rows, c) if p > 0 else torch.ones_like(res)
+    if p > 0:
+        frac = (keep > 0).float().mean().item()
+        assert abs(frac - (1 - p)) < 0.02 and torch.all((keep == 0) | ((keep - 1 / (1 - p)).abs() < 1e-6))
+    out = []
+    for fused in (True, False):
+        xi, ri = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+        norm.zero_grad()
+        y = f.dropout_add_layer_norm(xi, ri, norm, p, rng) if fused else norm(ri + xi.float() * keep)
+        y.backward(go)
+        out.append([y.detach(), xi.grad.float(), ri.grad, norm.weight.grad.clone(), norm.bias.grad.clone()])
+    tol = 2e-5 if xdtype == torch.float32 else 1e-2
+    for a, b_, name in zip(out[0], out[1], ("y", "gx", "gres", "dgamma", "dbeta")):
+        t = tol if name == "gx" else 2e-5
+        assert (a - b_).abs().max().item() <= t * b_.abs().max().item() + 1e-6, (name, (a - b_).abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,p", [(8200, 0.0), (515, 0.1)])
+def test_fused_linear_bias_relu_dropout(dev, dtype, rows, p):
+    """dropout(relu(x W^T + b)): GEMM + one fused pass == the three-op formulation with the same mask; gradients incl. bias."""
+    from ocpg_amd.models.ops.functions import fused_ln_func as f
+    torch.manual_seed(0)
+    k, c = 64, 1024 + 8
+    x = torch.randn(rows, k, device=dev).to(dtype)
+    w = (torch.randn(c, k, device=dev) * 0.2).to(dtype)
+    b = torch.randn(c, device=dev).to(dtype)
+    go = torch.randn(rows, c, device=dev).to(dtype)
+    rng = (99, 7)
+    keep = _probe_keep_mask(rows, c, p, rng, dev).to(dtype) if p > 0 else torch.ones(rows, c, device=dev, dtype=dtype)
+    out = []
+    for fused in (True, False):
+        xi, wi, bi = (t.clone().requires_grad_(True) for t in (x, w, b))
+        h = f.LinearBiasReluDropout.apply(xi, wi, bi, p, rng, 1 if rows < 4096 else 5) if fused else torch.relu(torch.nn.functional.linear(xi, wi, bi)) * keep
+        h.backward(go)
+        out.append([h.detach().float(), xi.grad.float(), wi.grad.float(), bi.grad.float()])
+    for a, b_, name in zip(out[0], out[1], ("h", "gx", "gw", "gb")):
+        if dtype == torch.float32:
+            assert (a - b_).abs().max().item() <= 2e-5 * b_.abs().max().item() + 1e-6, (name, (a - b_).abs().max().item(), b_.abs().max().item())
+        else:   # bf16: the bias is added after (fused) vs before (addmm) the rounding of the GEMM result; a pre-activation within
+            #     an ulp of zero flips its ReLU (~0.25 % of the units here: ~3-5 % of the gradient norm) -> norm-relative bound
+            assert (a - b_).norm().item() <= 6e-2 * b_.norm().item(), (name, (a - b_).norm().item(), b_.norm().item())
+
+
 @pytest.mark.parametrize("num_classes", [1, 7])
 def test_hip_matcher_cost_equals_torch_formulas(dev, num_classes):
     """csrc/matcher.hip (one launch for all layers / clips / queries, strided mask view) against the matcher's tensor-op
