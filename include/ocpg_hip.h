@@ -155,18 +155,23 @@ int ocpg_matcher_cost_f32(const float* logits, const float* boxes, const float* 
 /* Transformer-layer glue (models/deformable_transformer.py:236-257,313-336), one HBM pass each way:
  *   y = LayerNorm(res + dropout(x)):  x [R,C] (x_dtype 0 fp32 / 1 bf16), res / y fp32, C % 4 == 0, C <= 2048; mean, rstd [R]
  *     are kept for the backward, which recomputes the dropout mask from (seed, offset) (Philox-4x32-10, counter = element/4);
- *     bwd: gx (x's dtype, may be NULL), gres (may be NULL) fully written; dgamma / dbeta [C] ACCUMULATED (caller zeroes).
+ *     bwd: gx (x's dtype, may be NULL), gres (may be NULL) fully written; dgb_part [slots, 2, C] partial (dgamma, dbeta) sums,
+ *     fully written, slots = ocpg_dropout_add_ln_bwd_slots(R); the caller sums over the slots.
  *   h = dropout(relu(a + bias)):  a, bias, h share dtype (0 fp32 / 1 bf16), h may alias a; bwd from h only:
- *     ga = gh / (1-p) where h > 0; dbias [C] fp32 ACCUMULATED (caller zeroes). */
+ *     ga = gh / (1-p) where h > 0; dbias_part [slots, C] fp32 partial column sums, fully written, slots =
+ *     ocpg_bias_relu_dropout_bwd_slots(R, C, dtype); the caller sums over the slots. */
 int ocpg_dropout_add_ln_fwd(const void* x, const float* res, const float* gamma, const float* beta, long long R, int C, float eps, float p,
                             unsigned long long seed, unsigned long long offset, int x_dtype, float* y, float* mean, float* rstd,
                             void* stream);
 int ocpg_dropout_add_ln_bwd(const float* gy, const void* x, const float* res, const float* gamma, const float* mean, const float* rstd,
                             long long R, int C, float p, unsigned long long seed, unsigned long long offset, int x_dtype, void* gx, float* gres,
-                            float* dgamma, float* dbeta, void* stream);
+                            float* dgb_part, void* stream);
+long long ocpg_dropout_add_ln_bwd_slots(long long R);
 int ocpg_bias_relu_dropout_fwd(const void* a, const void* bias, long long R, int C, float p, unsigned long long seed,
                                unsigned long long offset, int dtype, void* h, void* stream);
-int ocpg_bias_relu_dropout_bwd(const void* gh, const void* h, long long R, int C, float p, int dtype, void* ga, float* dbias, void* stream);
+int ocpg_bias_relu_dropout_bwd(const void* gh, const void* h, long long R, int C, float p, int dtype, void* ga, float* dbias_part,
+                               void* stream);
+long long ocpg_bias_relu_dropout_bwd_slots(long long R, int C, int dtype);
 
 /* library / build identification: returns e.g. "ocpg_hip gfx950 r1" */
 const char* ocpg_hip_version(void);

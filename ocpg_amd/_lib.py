@@ -34,9 +34,11 @@ SIGNATURES = {
     "ocpg_matcher_cost_f32": [_vp] * 3 + [ctypes.c_longlong] * 4 + [_vp] * 4 + [_int] * 7 + [ctypes.c_float] * 5 + [_vp] * 4,
     "ocpg_dropout_add_ln_fwd": [_vp] * 4 + [ctypes.c_longlong, _int, ctypes.c_float, ctypes.c_float, ctypes.c_ulonglong, ctypes.c_ulonglong, _int]
                                + [_vp] * 4,
-    "ocpg_dropout_add_ln_bwd": [_vp] * 6 + [ctypes.c_longlong, _int, ctypes.c_float, ctypes.c_ulonglong, ctypes.c_ulonglong, _int] + [_vp] * 5,
+    "ocpg_dropout_add_ln_bwd": [_vp] * 6 + [ctypes.c_longlong, _int, ctypes.c_float, ctypes.c_ulonglong, ctypes.c_ulonglong, _int] + [_vp] * 4,
+    "ocpg_dropout_add_ln_bwd_slots": [ctypes.c_longlong],
     "ocpg_bias_relu_dropout_fwd": [_vp, _vp, ctypes.c_longlong, _int, ctypes.c_float, ctypes.c_ulonglong, ctypes.c_ulonglong, _int, _vp, _vp],
     "ocpg_bias_relu_dropout_bwd": [_vp, _vp, ctypes.c_longlong, _int, ctypes.c_float, _int, _vp, _vp, _vp],
+    "ocpg_bias_relu_dropout_bwd_slots": [ctypes.c_longlong, _int, _int],
     "ocpg_im2col3x3_nhwc": [_vp] + [_int] * 6 + [_vp, _int, _vp],
     "ocpg_col2im3x3_nhwc": [_vp] + [_int] * 6 + [_vp, _int, _vp],
     "ocpg_win_attn_fwd": [_vp, _vp, _vp, ctypes.c_float] + [_int] * 5 + [_vp, _vp, _int, _vp],
@@ -58,6 +60,8 @@ def lib():
             fn.restype = ctypes.c_int
         L.ocpg_hip_version.restype = ctypes.c_char_p
         L.ocpg_gemm_plans.restype = ctypes.c_longlong
+        L.ocpg_bias_relu_dropout_bwd_slots.restype = ctypes.c_longlong
+        L.ocpg_dropout_add_ln_bwd_slots.restype = ctypes.c_longlong
         _lib = L
     return _lib
 

@@ -121,8 +121,7 @@ template <typename XT, int NCH>
 __global__ __launch_bounds__(256) void dal_bwd(const float* __restrict__ gy, const XT* __restrict__ x, const float* __restrict__ res,
                                                const float* __restrict__ gamma, const float* __restrict__ mean,
                                                const float* __restrict__ rstd, long long R, int C, uint32_t thr, float scale, uint64_t seed,
-                                               uint64_t offset, XT* __restrict__ gx, float* __restrict__ gres, float* __restrict__ dgamma,
-                                               float* __restrict__ dbeta) {
+                                               uint64_t offset, XT* __restrict__ gx, float* __restrict__ gres, float* __restrict__ dgamma) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = C / 4;
   float dg[NCH][4], db[NCH][4], g[NCH][4];
@@ -170,8 +169,11 @@ __global__ __launch_bounds__(256) void dal_bwd(const float* __restrict__ gy, con
       }
     }
   }
-  // flush d(gamma), d(beta): reduce the 4 waves of the workgroup through LDS, one atomic per column per workgroup
+  // flush d(gamma), d(beta): reduce the 4 waves of the workgroup through LDS, then ONE plain store per column into this
+  // workgroup's row of the partial buffer dgb_part [gridDim.x, 2, C] (the caller sums the rows; same-address float atomics
+  // from 1024 workgroups serialise)
   __shared__ float red[2][4][64 * 4];
+  float* part = dgamma + (long long)blockIdx.x * 2 * C;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     if (64 * i >= nch) break;               // uniform
@@ -182,47 +184,93 @@ __global__ __launch_bounds__(256) void dal_bwd(const float* __restrict__ gy, con
     const int col = threadIdx.x;            // 256 threads <-> the 256 columns of chunk group i
     const int ch = col / 4 + 64 * i;
     if (ch < nch) {
-      atomicAdd(dgamma + 64 * 4 * i + col, red[0][0][col] + red[0][1][col] + red[0][2][col] + red[0][3][col]);
-      atomicAdd(dbeta + 64 * 4 * i + col, red[1][0][col] + red[1][1][col] + red[1][2][col] + red[1][3][col]);
+      part[64 * 4 * i + col] = red[0][0][col] + red[0][1][col] + red[0][2][col] + red[0][3][col];
+      part[C + 64 * 4 * i + col] = red[1][0][col] + red[1][1][col] + red[1][2][col] + red[1][3][col];
     }
   }
 }
 
-// h = dropout(relu(a + bias)) ; lane = 4 consecutive columns
-template <typename T>
-__global__ __launch_bounds__(256) void brd_fwd(const T* __restrict__ a, const T* __restrict__ bias, long long total4, int C, uint32_t thr,
-                                               float scale, uint64_t seed, uint64_t offset, T* __restrict__ h) {
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
-    const int col = (int)((i * 4) % C);
-    float av[4], bv[4], k[4], o[4];
-    IO<T>::load4(a + i * 4, av);
-    IO<T>::load4(bias + col, bv);
-    keep4(seed, offset, (uint64_t)i, thr, scale, k);
+// 16-byte lane accesses: V groups of 4 columns per lane (fp32: V = 1; bf16: V = 2 when C % 8 == 0)
+template <typename T, int V> struct Wide {
+  static __device__ __forceinline__ void load(const T* p, float (&f)[V][4]) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = fmaxf(av[j] + bv[j], 0.f) * k[j];
-    IO<T>::store4(h + i * 4, o);
+    for (int v = 0; v < V; ++v) IO<T>::load4(p + 4 * v, f[v]);
+  }
+  static __device__ __forceinline__ void store(T* p, const float (&f)[V][4]) {
+#pragma unroll
+    for (int v = 0; v < V; ++v) IO<T>::store4(p + 4 * v, f[v]);
+  }
+};
+template <> struct Wide<__hip_bfloat16, 2> {
+  static __device__ __forceinline__ void load(const __hip_bfloat16* p, float (&f)[2][4]) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[i / 2][2 * (i % 2)] = __uint_as_float(w[i] << 16); f[i / 2][2 * (i % 2) + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  }
+  static __device__ __forceinline__ void store(__hip_bfloat16* p, const float (&f)[2][4]) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const __hip_bfloat16 lo = __float2bfloat16(f[i / 2][2 * (i % 2)]), hi = __float2bfloat16(f[i / 2][2 * (i % 2) + 1]);
+      w[i] = (uint32_t)(*reinterpret_cast<const uint16_t*>(&lo)) | ((uint32_t)(*reinterpret_cast<const uint16_t*>(&hi)) << 16);
+    }
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+
+// h = dropout(relu(a + bias)) ; lane = 4*V consecutive columns (the generator's counter stays "element index / 4")
+template <typename T, int V>
+__global__ __launch_bounds__(256) void brd_fwd(const T* __restrict__ a, const T* __restrict__ bias, long long totalv, int C, uint32_t thr,
+                                               float scale, uint64_t seed, uint64_t offset, T* __restrict__ h) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < totalv; i += (long long)gridDim.x * 256) {
+    const int col = (int)((i * 4 * V) % C);
+    float av[V][4], bv[V][4], o[V][4];
+    Wide<T, V>::load(a + i * 4 * V, av);
+    Wide<T, V>::load(bias + col, bv);
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      float k[4];
+      keep4(seed, offset, (uint64_t)i * V + v, thr, scale, k);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[v][j] = fmaxf(av[v][j] + bv[v][j], 0.f) * k[j];
+    }
+    Wide<T, V>::store(h + i * 4 * V, o);
   }
 }
 
-// ga = (h > 0) ? gh * scale : 0 ; dbias[c] += sum_r ga[r, c]  (workgroup = 256 lanes x 4 columns = 1024 columns per sweep)
-template <typename T>
+// ga = (h > 0) ? gh * scale : 0 ; dbias_part[slot, c] = sum over the rows of that slot of ga[r, c]  (the caller sums the slots:
+// 1024 workgroups x 1024 columns of same-address float atomics cost 3x the streaming time, measured).  A lane owns its
+// columns for all the rows its slot visits (rows strided by the grid).
+template <typename T, int V>
 __global__ __launch_bounds__(256) void brd_bwd(const T* __restrict__ gh, const T* __restrict__ h, long long R, int C, float scale,
                                                T* __restrict__ ga, float* __restrict__ dbias) {
-  for (int c0 = 0; c0 < C; c0 += 1024) {
-    const int col = c0 + threadIdx.x * 4;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    if (col < C) {
-      for (long long r = blockIdx.x; r < R; r += gridDim.x) {
-        float gv[4], hv[4], o[4];
-        IO<T>::load4(gh + r * C + col, gv);
-        IO<T>::load4(h + r * C + col, hv);
+  const int lpr = C / (4 * V);                                  // lanes per row
+  const int rpi = lpr >= 256 ? 1 : 256 / lpr;                   // rows per sweep of the workgroup (narrow matrices: several)
+  const int ro = lpr >= 256 ? 0 : threadIdx.x / lpr;
+  const int g0 = lpr >= 256 ? threadIdx.x : threadIdx.x % lpr;
+  if (ro >= rpi) return;
+  for (int g = g0; g < lpr; g += 256) {
+    const int col = g * 4 * V;
+    float acc[V][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { o[j] = hv[j] > 0.f ? gv[j] * scale : 0.f; acc[j] += o[j]; }
-        IO<T>::store4(ga + r * C + col, o);
-      }
+    for (int v = 0; v < V; ++v)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) atomicAdd(dbias + col + j, acc[j]);
+      for (int j = 0; j < 4; ++j) acc[v][j] = 0.f;
+    for (long long r = (long long)blockIdx.x * rpi + ro; r < R; r += (long long)gridDim.x * rpi) {
+      float gv[V][4], hv[V][4], o[V][4];
+      Wide<T, V>::load(gh + r * C + col, gv);
+      Wide<T, V>::load(h + r * C + col, hv);
+#pragma unroll
+      for (int v = 0; v < V; ++v)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o[v][j] = hv[v][j] > 0.f ? gv[v][j] * scale : 0.f; acc[v][j] += o[v][j]; }
+      Wide<T, V>::store(ga + r * C + col, o);
     }
+    // partial column sums of this (workgroup, row slot): plain stores, every element of dbias_part written exactly once
+    float* o = dbias + ((long long)blockIdx.x * rpi + ro) * C + col;
+#pragma unroll
+    for (int v = 0; v < V; ++v) *reinterpret_cast<float4*>(o + 4 * v) = make_float4(acc[v][0], acc[v][1], acc[v][2], acc[v][3]);
   }
 }
 
@@ -257,22 +305,26 @@ int ocpg_dropout_add_ln_fwd(const void* x, const float* res, const float* gamma,
   return e == hipSuccess ? 0 : -(int)e;
 }
 
+long long ocpg_dropout_add_ln_bwd_slots(long long R) {
+  const long long want = (R + 3) / 4;
+  return want < 1 ? 1 : (want < 1024 ? want : 1024);
+}
+
 int ocpg_dropout_add_ln_bwd(const float* gy, const void* x, const float* res, const float* gamma, const float* mean, const float* rstd,
                             long long R, int C, float p, unsigned long long seed, unsigned long long offset, int x_dtype, void* gx, float* gres,
-                            float* dgamma, float* dbeta, void* stream) {
+                            float* dgb_part, void* stream) {
   if (R < 0 || C <= 0 || C % 4 != 0 || C > 64 * 4 * NCH_MAX) return -1006;
   if (p < 0.f || p >= 1.f) return -1007;
   if (R == 0) return 0;
   if (!gy || !x || !res || !gamma || !mean || !rstd) return -1001;
-  if (!dgamma || !dbeta) return -1010;
+  if (!dgb_part) return -1010;
   const uint32_t thr = threshold(p);
   const float scale = 1.f / (1.f - p);
-  const long long want = (R + 3) / 4;
-  const unsigned grid = (unsigned)(want < 1024 ? want : 1024);
+  const unsigned grid = (unsigned)ocpg_dropout_add_ln_bwd_slots(R);
   hipStream_t st = (hipStream_t)stream;
   if (x_dtype != 0 && x_dtype != 1) return -1008;
   const int nc = (C + 255) / 256;
-#define DAL_BWD(XT_, N_) dal_bwd<XT_, N_><<<grid, 256, 0, st>>>(gy, (const XT_*)x, res, gamma, mean, rstd, R, C, thr, scale, seed, offset, (XT_*)gx, gres, dgamma, dbeta)
+#define DAL_BWD(XT_, N_) dal_bwd<XT_, N_><<<grid, 256, 0, st>>>(gy, (const XT_*)x, res, gamma, mean, rstd, R, C, thr, scale, seed, offset, (XT_*)gx, gres, dgb_part)
 #define DAL_BWD_T(XT_) do { if (nc <= 1) DAL_BWD(XT_, 1); else if (nc <= 2) DAL_BWD(XT_, 2); else if (nc <= 4) DAL_BWD(XT_, 4); else DAL_BWD(XT_, 8); } while (0)
   if (x_dtype == 0) DAL_BWD_T(float); else DAL_BWD_T(__hip_bfloat16);
   const hipError_t e = hipGetLastError();
@@ -288,15 +340,32 @@ int ocpg_bias_relu_dropout_fwd(const void* a, const void* bias, long long R, int
   if (!h) return -1010;
   const uint32_t thr = threshold(p);
   const float scale = 1.f / (1.f - p);
-  const long long total4 = R * C / 4;
-  const long long want = (total4 + 255) / 256;
+  const int V = (dtype == 1 && C % 8 == 0) ? 2 : 1;
+  const long long totalv = R * C / (4 * V);
+  const long long want = (totalv + 255) / 256;
   const unsigned grid = (unsigned)(want < 256 * 32 ? want : 256 * 32);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == 0) brd_fwd<float><<<grid, 256, 0, st>>>((const float*)a, (const float*)bias, total4, C, thr, scale, seed, offset, (float*)h);
-  else if (dtype == 1) brd_fwd<__hip_bfloat16><<<grid, 256, 0, st>>>((const __hip_bfloat16*)a, (const __hip_bfloat16*)bias, total4, C, thr, scale, seed, offset, (__hip_bfloat16*)h);
+  if (dtype == 0) brd_fwd<float, 1><<<grid, 256, 0, st>>>((const float*)a, (const float*)bias, totalv, C, thr, scale, seed, offset, (float*)h);
+  else if (dtype == 1 && V == 2) brd_fwd<__hip_bfloat16, 2><<<grid, 256, 0, st>>>((const __hip_bfloat16*)a, (const __hip_bfloat16*)bias, totalv, C, thr, scale, seed, offset, (__hip_bfloat16*)h);
+  else if (dtype == 1) brd_fwd<__hip_bfloat16, 1><<<grid, 256, 0, st>>>((const __hip_bfloat16*)a, (const __hip_bfloat16*)bias, totalv, C, thr, scale, seed, offset, (__hip_bfloat16*)h);
   else return -1008;
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
+}
+
+static int brd_rows_per_sweep(int C, int dtype) {
+  const int V = (dtype == 1 && C % 8 == 0) ? 2 : 1;
+  const int lpr = C / (4 * V);
+  return lpr >= 256 ? 1 : 256 / lpr;
+}
+static unsigned brd_grid(long long R, int C, int dtype) {
+  const long long want = (R + brd_rows_per_sweep(C, dtype) - 1) / brd_rows_per_sweep(C, dtype);
+  return (unsigned)(want < 1024 ? want : 1024);
+}
+
+long long ocpg_bias_relu_dropout_bwd_slots(long long R, int C, int dtype) {
+  if (R <= 0 || C <= 0 || C % 4 != 0) return 0;
+  return (long long)brd_grid(R, C, dtype) * brd_rows_per_sweep(C, dtype);
 }
 
 int ocpg_bias_relu_dropout_bwd(const void* gh, const void* h, long long R, int C, float p, int dtype, void* ga, float* dbias, void* stream) {
@@ -306,10 +375,12 @@ int ocpg_bias_relu_dropout_bwd(const void* gh, const void* h, long long R, int C
   if (!gh || !h) return -1001;
   if (!ga || !dbias) return -1010;
   const float scale = 1.f / (1.f - p);
-  const unsigned grid = (unsigned)(R < 1024 ? R : 1024);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == 0) brd_bwd<float><<<grid, 256, 0, st>>>((const float*)gh, (const float*)h, R, C, scale, (float*)ga, dbias);
-  else if (dtype == 1) brd_bwd<__hip_bfloat16><<<grid, 256, 0, st>>>((const __hip_bfloat16*)gh, (const __hip_bfloat16*)h, R, C, scale, (__hip_bfloat16*)ga, dbias);
+  const int V = (dtype == 1 && C % 8 == 0) ? 2 : 1;
+  const unsigned grid = brd_grid(R, C, dtype);
+  if (dtype == 0) brd_bwd<float, 1><<<grid, 256, 0, st>>>((const float*)gh, (const float*)h, R, C, scale, (float*)ga, dbias);
+  else if (dtype == 1 && V == 2) brd_bwd<__hip_bfloat16, 2><<<grid, 256, 0, st>>>((const __hip_bfloat16*)gh, (const __hip_bfloat16*)h, R, C, scale, (__hip_bfloat16*)ga, dbias);
+  else if (dtype == 1) brd_bwd<__hip_bfloat16, 1><<<grid, 256, 0, st>>>((const __hip_bfloat16*)gh, (const __hip_bfloat16*)h, R, C, scale, (__hip_bfloat16*)ga, dbias);
   else return -1008;
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;

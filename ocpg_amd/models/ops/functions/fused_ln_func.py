@@ -47,11 +47,12 @@ class DropoutAddLayerNorm(Function):
         gy = gy.reshape(r, c).float().contiguous()
         gx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
         gres = torch.empty_like(res2) if ctx.needs_input_grad[1] else None
-        dgb = torch.zeros((2, c), dtype=torch.float32, device=x2.device)
+        part = torch.empty((lib().ocpg_dropout_add_ln_bwd_slots(r), 2, c), dtype=torch.float32, device=x2.device)
         check(lib().ocpg_dropout_add_ln_bwd(gy.data_ptr(), x2.data_ptr(), res2.data_ptr(), gamma.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
                                             r, c, p, seed, offset, _DT[x2.dtype], None if gx is None else gx.data_ptr(),
-                                            None if gres is None else gres.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(), _st()),
+                                            None if gres is None else gres.data_ptr(), part.data_ptr(), _st()),
               "ocpg_dropout_add_ln_bwd")
+        dgb = part.sum(0)
         return (None if gx is None else gx.view(xshape), None if gres is None else gres.view(rshape), dgb[0], dgb[1], None, None, None)
 
 
@@ -76,9 +77,11 @@ class LinearBiasReluDropout(Function):
         r, c = h.shape
         gh = gh.to(h.dtype).contiguous()
         ga = torch.empty_like(h)
-        dbias = torch.zeros((c,), dtype=torch.float32, device=h.device)
-        check(lib().ocpg_bias_relu_dropout_bwd(gh.data_ptr(), h.data_ptr(), r, c, p, _DT[h.dtype], ga.data_ptr(), dbias.data_ptr(), _st()),
+        slots = lib().ocpg_bias_relu_dropout_bwd_slots(r, c, _DT[h.dtype])
+        part = torch.empty((slots, c), dtype=torch.float32, device=h.device)
+        check(lib().ocpg_bias_relu_dropout_bwd(gh.data_ptr(), h.data_ptr(), r, c, p, _DT[h.dtype], ga.data_ptr(), part.data_ptr(), _st()),
               "ocpg_bias_relu_dropout_bwd")
+        dbias = part.sum(0)
         gx = torch.mm(ga, w) if ctx.needs_input_grad[0] else None
         gw = weight_grad(ga, x2) if ctx.needs_input_grad[1] else None
         return gx, gw, dbias.to(h.dtype) if ctx.needs_input_grad[2] else None, None, None, None
