@@ -120,6 +120,12 @@ int ocpg_gemm(const void* A, const void* B, void* C, const void* bias, int dtype
               long long M, long long N, long long K, long long lda, long long ldb, long long ldc, long long batch,
               long long strideA, long long strideB, long long strideC, float alpha, float beta, void* stream);
 long long ocpg_gemm_plans(void);      /* number of cached plans (diagnostics) */
+/* D[M,N] = act(scale[n] * (A W^T)[m,n] + shift[n] (+ skip[m,n])): the 1x1 conv + FrozenBatchNorm2d affine (+ identity) (+ ReLU) of a
+ * Bottleneck (models/backbone.py:46-56 + torchvision's block) inside the GEMM epilogue (per-channel alpha vector, fp32 bias, ReLU,
+ * beta = 1 on the skip operand).  A [M,K], W [N,K], skip / D [M,N] dense row-major, dtype 0/1/2; scale, shift fp32 [N].
+ * Returns -1105 when hipBLASLt offers no kernel for the combination (fall back to ocpg_gemm + ocpg_bn_act_fwd). */
+int ocpg_gemm_bn_act(const void* A, const void* W, void* D, const float* scale, const float* shift, const void* skip, int relu, int dtype,
+                     long long M, long long N, long long K, void* stream);
 
 /* Mask-criterion losses, all decoder layers per call (fp32; replace the elementwise/reduction chains of
  * models/segmentation.py:203-211,253-315 as called from models/criterion.py:141-178).

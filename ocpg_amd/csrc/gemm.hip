@@ -24,10 +24,10 @@
 namespace {
 
 struct Key {
-  int dtype, out_dtype, ta, tb, bias, beta0;
+  int dtype, out_dtype, ta, tb, bias, beta0, epi;      // epi: bit0 ReLU, bit1 per-column alpha vector, bit2 fp32 bias
   int64_t m, n, k, lda, ldb, ldc, batch, sa, sb, sc;
   bool operator==(const Key& o) const {
-    return dtype == o.dtype && out_dtype == o.out_dtype && ta == o.ta && tb == o.tb && bias == o.bias && beta0 == o.beta0 && m == o.m &&
+    return dtype == o.dtype && out_dtype == o.out_dtype && ta == o.ta && tb == o.tb && bias == o.bias && beta0 == o.beta0 && epi == o.epi && m == o.m &&
            n == o.n && k == o.k && lda == o.lda && ldb == o.ldb && ldc == o.ldc && batch == o.batch && sa == o.sa && sb == o.sb && sc == o.sc;
   }
 };
@@ -35,7 +35,7 @@ struct KeyHash {
   size_t operator()(const Key& k) const {
     uint64_t h = 1469598103934665603ull;
     auto mix = [&h](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
-    mix(k.dtype); mix(k.out_dtype); mix(k.ta); mix(k.tb); mix(k.bias); mix(k.beta0); mix(k.m); mix(k.n); mix(k.k); mix(k.lda); mix(k.ldb);
+    mix(k.dtype); mix(k.out_dtype); mix(k.ta); mix(k.tb); mix(k.bias); mix(k.beta0); mix(k.epi); mix(k.m); mix(k.n); mix(k.k); mix(k.lda); mix(k.ldb);
     mix(k.ldc); mix(k.batch); mix(k.sa); mix(k.sb); mix(k.sc);
     return (size_t)h;
   }
@@ -80,10 +80,17 @@ Plan build(State& s, const Key& key) {
   const hipblasOperation_t opa = key.tb ? HIPBLAS_OP_T : HIPBLAS_OP_N, opb = key.ta ? HIPBLAS_OP_T : HIPBLAS_OP_N;
   hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &opa, sizeof(opa));
   hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &opb, sizeof(opb));
-  if (key.bias) {
-    const hipblasLtEpilogue_t ep = HIPBLASLT_EPILOGUE_BIAS;
+  if (key.bias || (key.epi & 1)) {
+    const hipblasLtEpilogue_t ep = key.bias ? ((key.epi & 1) ? HIPBLASLT_EPILOGUE_RELU_BIAS : HIPBLASLT_EPILOGUE_BIAS) : HIPBLASLT_EPILOGUE_RELU;
     hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &ep, sizeof(ep));
-    hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &in, sizeof(in));
+    if (key.bias) {
+      const hipDataType bt = (key.epi & 4) ? HIP_R_32F : in;
+      hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof(bt));
+    }
+  }
+  if (key.epi & 2) {      // alpha = device vector over the rows of the column-major D = the columns (output channels) of C
+    const int32_t pm = HIPBLASLT_POINTER_MODE_ALPHA_DEVICE_VECTOR_BETA_HOST;
+    if (hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_POINTER_MODE, &pm, sizeof(pm)) != HIPBLAS_STATUS_SUCCESS) { p.status = -1106; return p; }
   }
   // A' = B: stored row-major [K,N] (ldb) = column-major [N,K]; with transB stored [N,K] = column-major [K,N]
   const int64_t a_rows = key.tb ? key.k : key.n, a_cols = key.tb ? key.n : key.k;
@@ -124,7 +131,7 @@ extern "C" int ocpg_gemm(const void* A, const void* B, void* C, const void* bias
     if (hipblasLtCreate(&s.handle) != HIPBLAS_STATUS_SUCCESS) return -1100;
     if (hipMalloc(&s.workspace, kWorkspaceBytes) != hipSuccess) return -1099;
   }
-  const Key key{dtype, out_dtype, transA != 0, transB != 0, bias != nullptr, beta == 0.f, M, N, K, lda, ldb, ldc, batch,
+  const Key key{dtype, out_dtype, transA != 0, transB != 0, bias != nullptr, beta == 0.f, 0, M, N, K, lda, ldb, ldc, batch,
                 batch > 1 ? strideA : 0, batch > 1 ? strideB : 0, batch > 1 ? strideC : 0};
   auto it = s.plans.find(key);
   if (it == s.plans.end()) it = s.plans.emplace(key, build(s, key)).first;
@@ -133,6 +140,35 @@ extern "C" int ocpg_gemm(const void* A, const void* B, void* C, const void* bias
   if (bias) hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias));
   const hipblasStatus_t st = hipblasLtMatmul(s.handle, p.desc, &alpha, B, p.a, A, p.b, &beta, C, p.c, C, p.c, &p.algo, s.workspace,
                                              p.workspace, (hipStream_t)stream);
+  return st == HIPBLAS_STATUS_SUCCESS ? 0 : -1200 - (int)st;
+}
+
+// D[M,N] = act(scale[n] * (A W^T)[m,n] + shift[n] (+ skip[m,n]))  -- 1x1 conv + frozen-BN affine (+ residual) (+ ReLU) in the GEMM's
+// epilogue: A [M,K] (lda = K), W [N,K], skip / D [M,N] dense; scale, shift fp32 [N].  Returns -1105 when hipBLASLt has no
+// kernel for that combination (the caller then runs GEMM + bn_act).
+extern "C" int ocpg_gemm_bn_act(const void* A, const void* W, void* D, const float* scale, const float* shift, const void* skip, int relu,
+                                int dtype, long long M, long long N, long long K, void* stream) {
+  if (dtype < 0 || dtype > 2) return -1010;
+  if (M <= 0 || N <= 0 || K <= 0) return -1006;
+  if (!A) return -1001;
+  if (!W) return -1002;
+  if (!D) return -1003;
+  if (!scale || !shift) return -1004;
+  State& s = state();
+  std::lock_guard<std::mutex> lock(s.mu);
+  if (!s.handle) {
+    if (hipblasLtCreate(&s.handle) != HIPBLAS_STATUS_SUCCESS) return -1100;
+    if (hipMalloc(&s.workspace, kWorkspaceBytes) != hipSuccess) return -1099;
+  }
+  const Key key{dtype, dtype, 0, 1, 1, skip == nullptr, (relu ? 1 : 0) | 2 | 4, M, N, K, K, K, N, 1, 0, 0, 0};
+  auto it = s.plans.find(key);
+  if (it == s.plans.end()) it = s.plans.emplace(key, build(s, key)).first;
+  Plan& p = it->second;
+  if (p.status) return p.status;
+  hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &shift, sizeof(shift));
+  const float beta = skip ? 1.f : 0.f;
+  const hipblasStatus_t st = hipblasLtMatmul(s.handle, p.desc, scale, W, p.a, A, p.b, &beta, skip ? skip : D, p.c, D, p.c, &p.algo,
+                                             s.workspace, p.workspace, (hipStream_t)stream);
   return st == HIPBLAS_STATUS_SUCCESS ? 0 : -1200 - (int)st;
 }
 

@@ -6,6 +6,8 @@ Replaces torchvision Bottleneck's conv1+bn1+relu, conv3+bn3(+identity)+relu and 
 runs them (models/backbone.py:46-56 FrozenBatchNorm2d + nn.Conv2d).  The step is launch-bound on the host: one Python
 autograd node and 2 (forward) / 3-4 (backward) C calls replace two nodes and ~10 tensor-view ops per layer.
 """
+import os
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -14,6 +16,7 @@ from ...._lib import check, lib
 
 _DT = {torch.float32: 0, torch.bfloat16: 1}
 _CL = torch.channels_last
+EPILOGUE = os.environ.get("OCPG_GEMM_EPILOGUE", "1") != "0"     # A/B switch: BN affine / skip / ReLU in the GEMM epilogue
 
 
 def eligible(x, conv):
@@ -31,16 +34,22 @@ class Conv1x1BNAct(Function):
         L = lib()
         st = torch.cuda.current_stream().cuda_stream
         y = torch.empty((n, co, h, wd), dtype=x.dtype, device=x.device, memory_format=_CL)
-        # y[m, co] = x[m, c] w[co, c]^T
-        rc = L.ocpg_gemm(x.data_ptr(), w.data_ptr(), y.data_ptr(), None, dt, dt, 0, 1, m, co, c, c, c, co, 1, 0, 0, 0, 1.0, 0.0, st)
-        if rc:
-            check(rc, "ocpg_gemm")
         if skip is not None and (skip.dtype != x.dtype or not skip.is_contiguous(memory_format=_CL)):
             skip = skip.to(x.dtype).contiguous(memory_format=_CL)
-        rc = L.ocpg_bn_act_fwd(y.data_ptr(), scale.data_ptr(), shift.data_ptr(), None if skip is None else skip.data_ptr(), y.data_ptr(),
-                               m, co, 1, int(relu), dt, st)
-        if rc:
-            check(rc, "ocpg_bn_act_fwd")
+        rc = -1105
+        if EPILOGUE:    # y[m, co] = act(scale[co] * x[m, c] w[co, c]^T + shift[co] (+ skip)) inside the GEMM
+            rc = L.ocpg_gemm_bn_act(x.data_ptr(), w.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                    None if skip is None else skip.data_ptr(), int(relu), dt, m, co, c, st)
+            if rc and rc != -1105:
+                check(rc, "ocpg_gemm_bn_act")
+        if rc:          # no epilogue kernel for this shape: GEMM, then the frozen-BN kernel in place
+            rc = L.ocpg_gemm(x.data_ptr(), w.data_ptr(), y.data_ptr(), None, dt, dt, 0, 1, m, co, c, c, c, co, 1, 0, 0, 0, 1.0, 0.0, st)
+            if rc:
+                check(rc, "ocpg_gemm")
+            rc = L.ocpg_bn_act_fwd(y.data_ptr(), scale.data_ptr(), shift.data_ptr(), None if skip is None else skip.data_ptr(), y.data_ptr(),
+                                   m, co, 1, int(relu), dt, st)
+            if rc:
+                check(rc, "ocpg_bn_act_fwd")
         ctx.save_for_backward(x, w, y, scale)
         ctx.meta = (bool(relu), skip is not None, splits)
         return y
