@@ -179,6 +179,13 @@ int ocpg_bias_relu_dropout_bwd(const void* gh, const void* h, long long R, int C
                                void* stream);
 long long ocpg_bias_relu_dropout_bwd_slots(long long R, int C, int dtype);
 
+/* Dtype cast of MANY dense tensors in one launch -- replaces the per-parameter autocast casts and the per-parameter
+ * gradient casts of an AMP step (torch.cuda.amp as used by engine.py:49-62).  Device tables (int64): srcs / dsts = element
+ * pointers, numels, chunk_prefix [n+1] = prefix sum of ceil(numel / 2048); total_chunks = chunk_prefix[n].
+ * dtype codes: 0 fp32, 1 bf16, 2 fp16; supported pairs: fp32 <-> bf16, fp32 <-> fp16. */
+int ocpg_multi_cast(const long long* srcs, const long long* dsts, const long long* numels, const long long* chunk_prefix, int n,
+                    long long total_chunks, int src_dtype, int dst_dtype, void* stream);
+
 /* library / build identification: returns e.g. "ocpg_hip gfx950 r1" */
 const char* ocpg_hip_version(void);
 

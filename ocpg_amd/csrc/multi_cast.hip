@@ -1,0 +1,74 @@
+// One launch for the dtype cast of MANY tensors (the autocast working copies of all parameters, and their gradients back).
+//
+// Under autocast the reference casts every Conv2d / Linear weight to half precision with its own kernel per use and casts
+// every weight gradient back with another (torch.cuda.amp, engine.py:49-62): ~250 + ~370 tiny launches per step for
+// ResNet-101 + the transformer.  torch._foreach_copy_ does not fuse copies whose source and destination dtypes differ
+// (it loops), so amp_cache's "one cast per forward" was one autograd node but still hundreds of launches.  This kernel
+// takes a device table of (source, destination, element count) and a prefix of 2048-element chunks; each workgroup finds
+// its tensor by binary search and moves one chunk, 16 bytes per lane on the wide side.
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ocpg_hip.h"
+
+namespace {
+
+constexpr int CHUNK = 2048;     // elements per workgroup: 256 lanes x 8
+
+template <typename T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<__hip_bfloat16>(__hip_bfloat16 v) { return __bfloat162float(v); }
+template <> __device__ __forceinline__ float to_f<__half>(__half v) { return __half2float(v); }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ __hip_bfloat16 from_f<__hip_bfloat16>(float v) { return __float2bfloat16(v); }
+template <> __device__ __forceinline__ __half from_f<__half>(float v) { return __float2half_rn(v); }
+
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void multi_cast(const long long* __restrict__ srcs, const long long* __restrict__ dsts,
+                                                  const long long* __restrict__ numels, const long long* __restrict__ chunk_prefix, int n) {
+  const long long blk = blockIdx.x;
+  int lo = 0, hi = n;                       // largest t with chunk_prefix[t] <= blk
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (chunk_prefix[mid] <= blk) lo = mid; else hi = mid;
+  }
+  const S* s = reinterpret_cast<const S*>(srcs[lo]);
+  D* d = reinterpret_cast<D*>(dsts[lo]);
+  const long long count = numels[lo];
+  const long long base = (blk - chunk_prefix[lo]) * CHUNK + (long long)threadIdx.x * 8;
+  if (base + 8 <= count && ((reinterpret_cast<uintptr_t>(s + base) | reinterpret_cast<uintptr_t>(d + base)) & 15) == 0) {
+    S in[8];
+    D out[8];
+    if constexpr (sizeof(S) == 4) { *reinterpret_cast<uint4*>(in) = *reinterpret_cast<const uint4*>(s + base); *reinterpret_cast<uint4*>(in + 4) = *reinterpret_cast<const uint4*>(s + base + 4); }
+    else *reinterpret_cast<uint4*>(in) = *reinterpret_cast<const uint4*>(s + base);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = from_f<D>(to_f<S>(in[i]));
+    if constexpr (sizeof(D) == 4) { *reinterpret_cast<uint4*>(d + base) = *reinterpret_cast<uint4*>(out); *reinterpret_cast<uint4*>(d + base + 4) = *reinterpret_cast<uint4*>(out + 4); }
+    else *reinterpret_cast<uint4*>(d + base) = *reinterpret_cast<uint4*>(out);
+  } else {
+    for (long long i = base; i < base + 8 && i < count; ++i) d[i] = from_f<D>(to_f<S>(s[i]));
+  }
+}
+
+}  // namespace
+
+extern "C" int ocpg_multi_cast(const long long* srcs, const long long* dsts, const long long* numels, const long long* chunk_prefix, int n,
+                               long long total_chunks, int src_dtype, int dst_dtype, void* stream) {
+  if (n < 0 || total_chunks < 0) return -1006;
+  if (n == 0 || total_chunks == 0) return 0;
+  if (!srcs || !dsts || !numels || !chunk_prefix) return -1001;
+  if (total_chunks > 2147483647LL) return -1007;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned g = (unsigned)total_chunks;
+#define MC(S_, D_) multi_cast<S_, D_><<<g, 256, 0, st>>>(srcs, dsts, numels, chunk_prefix, n)
+  if (src_dtype == 0 && dst_dtype == 1) MC(float, __hip_bfloat16);
+  else if (src_dtype == 0 && dst_dtype == 2) MC(float, __half);
+  else if (src_dtype == 1 && dst_dtype == 0) MC(__hip_bfloat16, float);
+  else if (src_dtype == 2 && dst_dtype == 0) MC(__half, float);
+  else return -1010;
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}

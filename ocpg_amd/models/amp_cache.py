@@ -24,27 +24,127 @@ GEMM_3X3 = os.environ.get("OCPG_GEMM_3X3", "0") != "0"     # A/B switch: 3x3 con
 SPLIT_K = os.environ.get("OCPG_SPLIT_K", "1") != "0"      # A/B switch: weight gradients over many rows as row-split batched GEMMs
 
 
+MULTI_CAST = True   # A/B switch: one HIP launch for all parameter casts / gradient casts (csrc/multi_cast.hip)
+_DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+_CHUNK = 2048
+
+
+def _dense(t):
+    """Non-overlapping and dense: an elementwise copy to a tensor with the same strides keeps the memory order."""
+    if t.is_contiguous():
+        return True
+    return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)
+
+
+def _same_layout(g, shape, strides):
+    return tuple(g.shape) == tuple(shape) and all(a == b or n == 1 for a, b, n in zip(g.stride(), strides, shape))
+
+
+class _CastPlan:
+    """Static part of the fused cast of one parameter set on one device: flat offsets (16-byte aligned), chunk prefix."""
+
+    def __init__(self, params, low_dtype):
+        self.low_dtype = low_dtype
+        self.shapes = [tuple(p.shape) for p in params]
+        self.strides = [p.stride() for p in params]
+        self.numels = [p.numel() for p in params]
+        self.offsets, off = [], 0
+        for n in self.numels:
+            self.offsets.append(off)
+            off += (n + 7) // 8 * 8
+        self.total = off
+        self.device = params[0].device
+        prefix = [0]
+        for n in self.numels:
+            prefix.append(prefix[-1] + (n + _CHUNK - 1) // _CHUNK)
+        self.chunks = prefix[-1]
+        self.meta = torch.tensor([self.numels + [0], prefix], dtype=torch.int64).to(self.device)      # [2, n+1]
+        # persistent working copies: the weights only change at optimizer.step, so re-writing the buffer in the next forward
+        # (through the raw pointer: no autograd version bump) can only ever store identical values under a live graph
+        self.low = torch.empty(self.total, dtype=low_dtype, device=self.device)
+        self.low_ptrs = torch.tensor([self.low.data_ptr() + o * self.low.element_size() for o in self.offsets], dtype=torch.int64).to(self.device)
+        self.src_ptrs_host = [p.data_ptr() for p in params]
+        self.src_ptrs = torch.tensor(self.src_ptrs_host, dtype=torch.int64).to(self.device)
+
+    def cast_params(self):
+        from .._lib import check, lib
+        check(lib().ocpg_multi_cast(self.src_ptrs.data_ptr(), self.low_ptrs.data_ptr(), self.meta[0].data_ptr(), self.meta[1].data_ptr(),
+                                    len(self.numels), self.chunks, 0, _DT[self.low_dtype], torch.cuda.current_stream().cuda_stream),
+              "ocpg_multi_cast")
+        low = self.low      # fresh view objects per forward (each forward's outputs carry their own autograd history)
+        return [low.as_strided(sh, st, o) for sh, st, o in zip(self.shapes, self.strides, self.offsets)]
+
+    def cast_grads(self, grads, idx):
+        """grads[i] (low precision, same layout as parameter i) for i in idx -> fp32 views of ONE fresh flat buffer.
+        The per-call pointer table goes up through a small ring of PINNED staging buffers (a pageable host->device copy
+        would stall the host until the stream drains, measured +7 ms per step)."""
+        from .._lib import check, lib
+        n = len(idx)
+        flat = torch.empty(self.total, dtype=torch.float32, device=self.device)
+        base = flat.data_ptr()
+        prefix = [0]
+        for i in idx:
+            prefix.append(prefix[-1] + (self.numels[i] + _CHUNK - 1) // _CHUNK)
+        ring = self.__dict__.get("_ring")
+        if ring is None:
+            cap = len(self.numels)
+            ring = self._ring = {"host": [torch.empty((4, cap), dtype=torch.int64).pin_memory() for _ in range(8)],
+                                 "dev": [torch.empty((4, cap), dtype=torch.int64, device=self.device) for _ in range(8)],
+                                 "event": [None] * 8, "next": 0}
+        k = ring["next"]
+        ring["next"] = (k + 1) % 8
+        if ring["event"][k] is not None:
+            ring["event"][k].synchronize()          # slot still in flight only if the host is 8 backward passes ahead
+        host, dev = ring["host"][k], ring["dev"][k]
+        host[:, :n] = torch.tensor([[grads[i].data_ptr() for i in idx], [base + 4 * self.offsets[i] for i in idx],
+                                    [self.numels[i] for i in idx], prefix[:-1]], dtype=torch.int64)
+        dev.copy_(host, non_blocking=True)
+        ev = ring["event"][k] = torch.cuda.Event()
+        ev.record()
+        # the last prefix entry (the total) is passed by value; the kernel's search never reads chunk_prefix[n]
+        check(lib().ocpg_multi_cast(dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), dev[3].data_ptr(), n, prefix[-1],
+                                    _DT[self.low_dtype], 0, torch.cuda.current_stream().cuda_stream), "ocpg_multi_cast")
+        return [flat.as_strided(self.shapes[i], self.strides[i], self.offsets[i]) for i in idx]
+
+
+class _NoPlan:
+    """Remembers that this parameter set cannot take the one-launch path (non-dense or non-fp32 members)."""
+
+    def __init__(self, ptrs):
+        self.src_ptrs_host = ptrs
+
+
 class FusedCast(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, dtype, *params):
-        outs = [torch.empty_like(p, dtype=dtype) for p in params]
-        torch._foreach_copy_(outs, list(params))
+    def forward(ctx, dtype, plan, *params):
         ctx.src_dtype = params[0].dtype
         ctx.src_strides = [p.stride() for p in params]
+        ctx.plan = plan
+        if plan is not None:
+            return tuple(plan.cast_params())
+        outs = [torch.empty_like(p, dtype=dtype) for p in params]
+        torch._foreach_copy_(outs, list(params))
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *grads):
-        idx = [i for i, g in enumerate(grads) if g is not None and ctx.needs_input_grad[i + 1]]
+        idx = [i for i, g in enumerate(grads) if g is not None and ctx.needs_input_grad[i + 2]]
         res = [None] * len(grads)
         if idx:
-            # gradients take the PARAMETER's strides (DDP's gradient-as-bucket-view layout contract: a channels-last
-            # 1x1 weight [Co,Ci,1,1] and its dense gradient share the memory order but not the nominal strides)
-            outs = [torch.empty_strided(grads[i].shape, ctx.src_strides[i], dtype=ctx.src_dtype, device=grads[i].device) for i in idx]
-            torch._foreach_copy_(outs, [grads[i] for i in idx])
-            for i, o in zip(idx, outs):
-                res[i] = o
-        return (None, *res)
+            plan = ctx.plan
+            fast = [i for i in idx if plan is not None and grads[i].dtype == plan.low_dtype and _same_layout(grads[i], plan.shapes[i], plan.strides[i])]
+            if fast:
+                for i, o in zip(fast, plan.cast_grads(grads, fast)):
+                    res[i] = o
+            slow = [i for i in idx if res[i] is None]
+            if slow:
+                # gradients take the PARAMETER's strides (DDP's gradient-as-bucket-view layout contract: a channels-last
+                # 1x1 weight [Co,Ci,1,1] and its dense gradient share the memory order but not the nominal strides)
+                outs = [torch.empty_strided(grads[i].shape, ctx.src_strides[i], dtype=ctx.src_dtype, device=grads[i].device) for i in slow]
+                torch._foreach_copy_(outs, [grads[i] for i in slow])
+                for i, o in zip(slow, outs):
+                    res[i] = o
+        return (None, None, *res)
 
 
 def lookup(p):
@@ -215,7 +315,17 @@ def scope(module):
     if not params:
         yield
         return
-    outs = FusedCast.apply(torch.get_autocast_dtype("cuda"), *params)
+    low = torch.get_autocast_dtype("cuda")
+    plan = None
+    if MULTI_CAST and low in (torch.bfloat16, torch.float16):
+        plans = module.__dict__.setdefault("_amp_cache_plans", {})
+        ptrs = [p.data_ptr() for p in params]
+        plan = plans.get(low)
+        if plan is None or plan.src_ptrs_host != ptrs:      # first use, or parameters (re)allocated (.to(), memory format, ...)
+            plan = plans[low] = _CastPlan(params, low) if all(_dense(p) and p.dtype == torch.float32 for p in params) else _NoPlan(ptrs)
+        if isinstance(plan, _NoPlan):
+            plan = None
+    outs = FusedCast.apply(low, plan, *params)
     _ACTIVE.update({id(p): o for p, o in zip(params, outs)})
     try:
         yield
