@@ -33,6 +33,15 @@ class MSO(nn.Module):
         return self.out_conv(pred_masks)
 
 
+def _conv_input(f, dt):
+    """A backbone feature as the input of an autocast conv: the reference's torch.cat([pm, f], 1) promotes the half-precision
+    feature to pm's fp32 and the conv casts it straight back -- a lossless round trip, skipped here (two full-map casts
+    forward, two backward per level)."""
+    if f.is_cuda and torch.is_autocast_enabled("cuda") and f.dtype == torch.get_autocast_dtype("cuda"):
+        return f
+    return f.to(dt)
+
+
 def _mso_forward_multi(self, pred_masks_list, image_features, stacked=False):
     """Refine several mask sets (one per decoder layer) that share the SAME backbone features.
 
@@ -46,13 +55,13 @@ def _mso_forward_multi(self, pred_masks_list, image_features, stacked=False):
     dt = pm.dtype
     assert pm.shape[-1] == f8.shape[-1], "First size wrong."
     w8 = lookup(self.conv1_1div8.weight)
-    shared8 = F.conv2d(F.relu(f8.to(dt)), w8[:, c:], lookup(self.conv1_1div8.bias), padding=1)
+    shared8 = F.conv2d(F.relu(_conv_input(f8, dt)), w8[:, c:], lookup(self.conv1_1div8.bias), padding=1)
     y = F.conv2d(F.relu(pm), w8[:, :c], None, padding=1) + shared8.repeat(n, 1, 1, 1)
     pm = pm + self.conv2_1div8(F.relu(y))
     pm = F.interpolate(pm, size=f4.shape[-2:], mode="bilinear", align_corners=False)
     assert pm.shape[-1] == f4.shape[-1], "Second size wrong."
     w4 = lookup(self.conv1_1div4.weight)
-    shared4 = F.conv2d(F.relu(f4.to(dt)), w4[:, c:], lookup(self.conv1_1div4.bias), padding=1)
+    shared4 = F.conv2d(F.relu(_conv_input(f4, dt)), w4[:, c:], lookup(self.conv1_1div4.bias), padding=1)
     y = F.conv2d(F.relu(pm), w4[:, :c], None, padding=1) + shared4.repeat(n, 1, 1, 1)
     pm = pm + self.conv2_1div4(F.relu(y))
     out = self.out_conv(pm)

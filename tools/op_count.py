@@ -28,7 +28,7 @@ for m in list(model.modules()) + list(crit.modules()):
 VIEW = {"view", "_unsafe_view", "reshape", "permute", "transpose", "t", "expand", "unsqueeze", "squeeze", "select", "slice", "detach", "alias",
         "as_strided", "unbind", "split", "split_with_sizes", "unflatten", "flatten", "view_as_real", "view_as_complex", "chunk", "unfold",
         "lift_fresh", "_reshape_alias", "empty", "empty_like", "empty_strided", "sym_size", "stride", "size", "numel", "is_same_size", "prim"}
-by_fn = collections.Counter(); by_line = collections.Counter()
+by_fn = collections.Counter(); by_line = collections.Counter(); copies = collections.Counter(); copy_elems = collections.Counter()
 counts = collections.Counter(); per_op = collections.defaultdict(collections.Counter)
 class Count(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
@@ -41,6 +41,10 @@ class Count(TorchDispatchMode):
             if f is not None:
                 by_fn["%s:%s" % (os.path.basename(f.f_code.co_filename), f.f_code.co_name)] += 1
                 by_line["%s:%d" % (os.path.basename(f.f_code.co_filename), f.f_lineno)] += 1
+                if name in ("clone", "copy_", "_to_copy", "cat", "stack", "fill_", "zeros", "zero_", "index_select", "gather"):
+                    big = max([a.numel() for a in args if isinstance(a, torch.Tensor)] + [0])
+                    copies["%s:%d %s" % (os.path.basename(f.f_code.co_filename), f.f_lineno, name)] += 1
+                    copy_elems["%s:%d %s" % (os.path.basename(f.f_code.co_filename), f.f_lineno, name)] += big
         return func(*args, **(kwargs or {}))
 def run():
     with torch.autocast("cuda", dtype=torch.bfloat16):
@@ -55,6 +59,7 @@ for k, v in counts.most_common(40):
     print("%5d  %-50s %s" % (v, k, " ".join("%s:%d" % kv for kv in per_op[k].most_common(8))))
 print("--- per function"); print("\n".join("%5d %s" % (v, k) for k, v in by_fn.most_common(45)))
 print("--- per line"); print("\n".join("%5d %s" % (v, k) for k, v in by_line.most_common(60)))
+print("--- copies by line (count, Melem)"); print("\n".join("%4d %8.2f %s" % (copies[k], v / 1e6, k) for k, v in copy_elems.most_common(45)))
 # autograd graph census
 seen, todo, types = set(), [loss.grad_fn], collections.Counter()
 while todo:
