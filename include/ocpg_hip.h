@@ -186,6 +186,18 @@ long long ocpg_bias_relu_dropout_bwd_slots(long long R, int C, int dtype);
 int ocpg_multi_cast(const long long* srcs, const long long* dsts, const long long* numels, const long long* chunk_prefix, int n,
                     long long total_chunks, int src_dtype, int dst_dtype, void* stream);
 
+/* Classification (sigmoid focal, alpha < 0 disables the alpha weighting) + L1 + GIoU losses of the matched queries, all layers
+ * per launch -- replaces SetCriterion.loss_labels / loss_boxes (models/criterion.py:46-107; sigmoid_focal_loss
+ * models/segmentation.py:134-160; util/box_ops.py:45-85).  logits [Lr,B,T,Q,K], boxes [Lr,B,T,Q,4] (cxcywh), src [Lr,B] int64
+ * matched query, valid [B,T] float, labels [B,T] int64 or NULL, tboxes [B,T,4], num_boxes: device scalar.
+ * loss / gloss [3, Lr] = (ce, bbox, giou);  bwd writes glogits and gboxes fully.  bad: optional malformed-box counter. */
+int ocpg_det_loss_fwd_f32(const float* logits, const float* boxes, const long long* src, const float* valid, const long long* labels,
+                          const float* tboxes, const float* num_boxes, float alpha, int Lr, int B, int T, int Q, int K, float* loss, int* bad,
+                          void* stream);
+int ocpg_det_loss_bwd_f32(const float* logits, const float* boxes, const long long* src, const float* valid, const long long* labels,
+                          const float* tboxes, const float* num_boxes, const float* gloss, float alpha, int Lr, int B, int T, int Q, int K,
+                          float* glogits, float* gboxes, void* stream);
+
 /* library / build identification: returns e.g. "ocpg_hip gfx950 r1" */
 const char* ocpg_hip_version(void);
 

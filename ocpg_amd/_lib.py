@@ -41,6 +41,8 @@ SIGNATURES = {
     "ocpg_bias_relu_dropout_bwd": [_vp, _vp, ctypes.c_longlong, _int, ctypes.c_float, _int, _vp, _vp, _vp],
     "ocpg_bias_relu_dropout_bwd_slots": [ctypes.c_longlong, _int, _int],
     "ocpg_multi_cast": [_vp] * 4 + [_int, ctypes.c_longlong, _int, _int, _vp],
+    "ocpg_det_loss_fwd_f32": [_vp] * 7 + [ctypes.c_float] + [_int] * 5 + [_vp] * 3,
+    "ocpg_det_loss_bwd_f32": [_vp] * 8 + [ctypes.c_float] + [_int] * 5 + [_vp] * 3,
     "ocpg_im2col3x3_nhwc": [_vp] + [_int] * 6 + [_vp, _int, _vp],
     "ocpg_col2im3x3_nhwc": [_vp] + [_int] * 6 + [_vp, _int, _vp],
     "ocpg_win_attn_fwd": [_vp, _vp, _vp, ctypes.c_float] + [_int] * 5 + [_vp, _vp, _int, _vp],

@@ -83,3 +83,40 @@ def proj_loss(x, region, weak):
     with torch.no_grad():
         tcmax, trmax, tcmean, trmean = region.amax(2), region.amax(3), weak.mean(2), weak.mean(3)
     return ProjLoss.apply(x, tcmax, trmax, tcmean, trmean)
+
+
+class DetLosses(Function):
+    """Focal classification + L1 + GIoU losses of the matched queries for all layers (csrc/det_loss.hip) -> [3, Lr]."""
+
+    @staticmethod
+    def forward(ctx, logits, boxes, src, valid, labels, tboxes, num_boxes, alpha, bad):
+        logits, boxes = logits.float().contiguous(), boxes.float().contiguous()
+        lr, b, t, q, k = logits.shape
+        src = src.to(torch.int64).contiguous()
+        valid, tboxes = valid.float().contiguous(), tboxes.float().contiguous()
+        labels = None if labels is None else labels.to(torch.int64).contiguous()
+        nb = num_boxes.float().reshape(1).contiguous()
+        loss = torch.empty((3, lr), dtype=torch.float32, device=logits.device)
+        check(lib().ocpg_det_loss_fwd_f32(logits.data_ptr(), boxes.data_ptr(), src.data_ptr(), valid.data_ptr(),
+                                          None if labels is None else labels.data_ptr(), tboxes.data_ptr(), nb.data_ptr(), float(alpha), lr, b, t, q,
+                                          k, loss.data_ptr(), None if bad is None else bad.data_ptr(), _st()), "ocpg_det_loss_fwd_f32")
+        ctx.save_for_backward(logits, boxes, src, valid, tboxes, nb, *(() if labels is None else (labels,)))
+        ctx.alpha = float(alpha)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gloss):
+        logits, boxes, src, valid, tboxes, nb, *rest = ctx.saved_tensors
+        labels = rest[0] if rest else None
+        lr, b, t, q, k = logits.shape
+        glogits, gboxes = torch.empty_like(logits), torch.empty_like(boxes)
+        check(lib().ocpg_det_loss_bwd_f32(logits.data_ptr(), boxes.data_ptr(), src.data_ptr(), valid.data_ptr(),
+                                          None if labels is None else labels.data_ptr(), tboxes.data_ptr(), nb.data_ptr(),
+                                          gloss.float().contiguous().data_ptr(), ctx.alpha, lr, b, t, q, k, glogits.data_ptr(), gboxes.data_ptr(), _st()),
+              "ocpg_det_loss_bwd_f32")
+        return glogits, gboxes, None, None, None, None, None, None, None
+
+
+def det_losses(logits, boxes, src, valid, labels, tboxes, num_boxes, alpha, bad=None):
+    return DetLosses.apply(logits, boxes, src, valid, labels, tboxes, num_boxes, alpha, bad)

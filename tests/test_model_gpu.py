@@ -199,6 +199,55 @@ def test_hip_matcher_cost_equals_torch_formulas(dev, num_classes):
     flag.zero_()
 
 
+@pytest.mark.parametrize("num_classes", [1, 7])
+def test_hip_det_losses_equal_torch_formulas(dev, num_classes):
+    """csrc/det_loss.hip (focal classification + L1 + GIoU, all layers per launch, GIoU gradient by forward-mode duals)
+    against the criterion's tensor-op formulation: the three losses per layer and the gradients w.r.t. logits and boxes;
+    invalid frames, multi-class labels, boxes that do not overlap the target (hull term active) and that contain it."""
+    import synth
+    import cases
+    from ocpg_amd.models import build_model, criterion as crit_mod
+    torch.manual_seed(0)
+    args = cases.default_args(device=str(dev), **cases.TINY)
+    _, crit, _ = build_model(args)
+    crit.to(dev)
+    crit.num_classes = num_classes
+    lr, b, t, q = 3, 2, 3, 5
+    targets = synth.synthetic_targets(b, t, 32, 48, dev)
+    targets[1]["valid"] = torch.tensor([1, 0, 1], device=dev)
+    targets[1]["labels"] = torch.tensor([3, 0, 5], device=dev)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    logits = torch.randn(lr, b, t, q, num_classes, device=dev, generator=gen) * 2
+    boxes = torch.rand(lr, b, t, q, 4, device=dev, generator=gen) * 0.3 + 0.1
+    boxes[0, 0, :, :, :2] = 0.85                       # far from the target: no intersection
+    boxes[1, 1, :, :, :] = torch.tensor([0.375, 0.375, 0.6, 0.6], device=dev)      # contains the target
+    src = torch.randint(0, q, (lr, b), device=dev, generator=gen)
+    nb = torch.tensor(5.0, device=dev)
+    w = torch.tensor([[1.0, 2.0, 3.0]], device=dev).t() * torch.arange(1, lr + 1, device=dev)
+    res = []
+    for on in (True, False):
+        crit_mod.HIP_DET_LOSSES = on
+        try:
+            lg, bx = logits.clone().requires_grad_(True), boxes.clone().requires_grad_(True)
+            if on:
+                from ocpg_amd.models.ops.functions import mask_loss_func
+                valid = torch.stack([tg["valid"] for tg in targets])
+                labels = None if num_classes == 1 else torch.stack([tg["labels"] for tg in targets])
+                det = mask_loss_func.det_losses(lg, bx, src, valid, labels, torch.stack([tg["boxes"] for tg in targets]), nb, crit.focal_alpha)
+            else:
+                ce = crit._labels_stacked(lg, src, targets, nb)
+                l1, gi = crit._boxes_stacked(bx, src, targets, nb)
+                det = torch.stack([ce, l1, gi])
+            g = torch.autograd.grad((det * w).sum(), (lg, bx))
+            res.append((det.detach(), g))
+        finally:
+            crit_mod.HIP_DET_LOSSES = True
+    (d1, g1), (d0, g0) = res
+    assert torch.allclose(d1, d0, rtol=2e-5, atol=1e-6), (d1, d0)
+    for a, b_, name in zip(g1, g0, ("logits", "boxes")):
+        assert (a - b_).abs().max().item() <= 5e-5 * b_.abs().max().item() + 1e-7, (name, (a - b_).abs().max().item(), b_.abs().max().item())
+
+
 @pytest.mark.parametrize("case", ["regular", "degenerate"])
 def test_hip_mask_losses_equal_torch_formulas(dev, case):
     """csrc/levelset.hip + csrc/proj.hip (all layers per launch) against the criterion's own tensor-op restatement of
