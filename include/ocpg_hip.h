@@ -198,6 +198,13 @@ int ocpg_det_loss_bwd_f32(const float* logits, const float* boxes, const long lo
                           const float* tboxes, const float* num_boxes, const float* gloss, float alpha, int Lr, int B, int T, int Q, int K,
                           float* glogits, float* gboxes, void* stream);
 
+/* Spectral gate of LFMResizeAdaptive (models/modules.py:44-50): out [N,2C,h,w] = [Re, Im](X * (1 - coef[n] * high)) for a complex64
+ * spectrum X [N,C,h,w] (interleaved re/im), coef [N], high [h*w]; bwd: dX complex [N,C,h,w] fully written, part
+ * [N, C * ceil(hw/256)] partial sums with dcoef[n] = sum(part[n]). */
+int ocpg_spectral_gate_fwd(const void* X, const float* coef, const float* high, int N, int C, int hw, float* out, void* stream);
+int ocpg_spectral_gate_bwd(const float* gout, const void* X, const float* coef, const float* high, int N, int C, int hw, void* dX, float* part,
+                           void* stream);
+
 /* library / build identification: returns e.g. "ocpg_hip gfx950 r1" */
 const char* ocpg_hip_version(void);
 

@@ -9,7 +9,11 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ..util.misc import memo
 from . import amp_cache
+from .ops.functions.spectral_func import spectral_gate
+
+FUSED_GATE = True       # A/B switch: fused spectral gate kernel
 
 
 class LFMResizeAdaptive(nn.Module):
@@ -36,12 +40,23 @@ class LFMResizeAdaptive(nn.Module):
         b, c, h, w = x.shape
         x = x.float()
         coef = self.fc(self.laplace(x).mean(dim=(2, 3))).view(b, 1, 1, 1)
+        # the Gaussian of level 0 and its chain of bilinear resizes depend only on the map sizes: memoised (util.misc.memo)
         if gauss_map is None:
-            high = self.make_gaussian(h // 2, w // 2, h, w, self.sigma, x.device)
+            key = ("gauss", h // 2, w // 2, h, w, float(self.sigma))
+            high = memo("lfm_gauss", key, x.device, lambda: self.make_gaussian(h // 2, w // 2, h, w, self.sigma, x.device))
         else:
-            high = F.interpolate(gauss_map, size=(h, w), mode="bilinear", align_corners=False)
-        spec = torch.fft.fft2(x) * (1 - coef.float() * high)
-        y = self.conv2(F.relu(self.conv1(torch.cat([spec.real, spec.imag], dim=1)))).float()
+            parent = getattr(gauss_map, "_ocpg_key", None)
+            key = None if parent is None else ("resized", parent, h, w)
+            high = memo("lfm_gauss", key, x.device, lambda: F.interpolate(gauss_map, size=(h, w), mode="bilinear", align_corners=False))
+        if key is not None:
+            high._ocpg_key = key
+        if x.is_cuda and FUSED_GATE:
+            # gate, real/imag split and concatenation in one pass (csrc/spectral.hip)
+            z = spectral_gate(torch.fft.fft2(x), coef.float().reshape(b), high.reshape(h, w))
+        else:
+            spec = torch.fft.fft2(x) * (1 - coef.float() * high)
+            z = torch.cat([spec.real, spec.imag], dim=1)
+        y = self.conv2(F.relu(self.conv1(z))).float()
         yr, yi = torch.chunk(y, 2, dim=1)
         y = torch.fft.ifft2(torch.complex(yr, yi), s=(h, w)).real.float()
         return x + y, high

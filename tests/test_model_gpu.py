@@ -199,6 +199,30 @@ def test_hip_matcher_cost_equals_torch_formulas(dev, num_classes):
     flag.zero_()
 
 
+def test_lfm_fused_spectral_gate(dev):
+    """LFMResizeAdaptive with the fused spectral-gate kernel == the tensor-op formulation (complex product, real/imag split,
+    cat): output, input gradient and every parameter gradient; first call (own Gaussian) and chained call (resized map)."""
+    from ocpg_amd.models import modules
+    torch.manual_seed(0)
+    lfm = modules.LFMResizeAdaptive(32, 7).to(dev)
+    x1 = torch.randn(3, 32, 23, 37, device=dev)
+    x2 = torch.randn(3, 32, 12, 19, device=dev)
+    res = []
+    for on in (True, False):
+        modules.FUSED_GATE = on
+        try:
+            a, b_ = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+            lfm.zero_grad()
+            y1, g = lfm(a)
+            y2, _ = lfm(b_, g)
+            (y1.square().mean() + y2.square().mean()).backward()
+            res.append([y1.detach(), y2.detach(), a.grad, b_.grad] + [p.grad.clone() for p in lfm.parameters()])
+        finally:
+            modules.FUSED_GATE = True
+    for u, v in zip(*res):
+        assert (u - v).abs().max().item() <= 2e-5 * v.abs().max().item() + 1e-7, ((u - v).abs().max().item(), v.abs().max().item())
+
+
 @pytest.mark.parametrize("num_classes", [1, 7])
 def test_hip_det_losses_equal_torch_formulas(dev, num_classes):
     """csrc/det_loss.hip (focal classification + L1 + GIoU, all layers per launch, GIoU gradient by forward-mode duals)
