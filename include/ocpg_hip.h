@@ -205,6 +205,13 @@ int ocpg_spectral_gate_fwd(const void* X, const float* coef, const float* high, 
 int ocpg_spectral_gate_bwd(const float* gout, const void* X, const float* coef, const float* high, int N, int C, int hw, void* dX, float* part,
                            void* stream);
 
+/* Heat-map-weighted cross entropy (masked_ce_loss, models/segmentation.py:177-201, via criterion.py:128-139), all layers:
+ * x [Lr, per_layer] logits, w / t [per_layer] = weight map and weighted target of the clip (shared by the layers),
+ * per_layer % 4 == 0.  fwd: part [Lr, 512] with loss[l] = sum(part[l]) / per_layer;  bwd: gx [Lr, per_layer] fully written. */
+int ocpg_masked_ce_fwd_f32(const float* x, const float* w, const float* t, int Lr, long long per_layer, float* part, void* stream);
+int ocpg_masked_ce_bwd_f32(const float* x, const float* w, const float* t, const float* gloss, int Lr, long long per_layer, float* gx,
+                           void* stream);
+
 /* library / build identification: returns e.g. "ocpg_hip gfx950 r1" */
 const char* ocpg_hip_version(void);
 

@@ -153,8 +153,10 @@ class SetCriterion(nn.Module):
             return (region_e / pixels + 0.00001 * (length(fg) + length(bg)) / pixels).mean(1)
 
         w_full, w_low = heat_weight(_sub(heat, s), region), heat_weight(_sub(heat, sl), region_low)
-        loss_mask = masked_ce(pm, w_full, weak_full)
-        loss_mask_low = masked_ce(pml, w_low, weak_low)
+        if pm.is_cuda and HIP_MASK_LOSSES and pm[0].numel() % 4 == 0 and pml[0].numel() % 4 == 0:
+            loss_mask, loss_mask_low = mask_loss_func.masked_ce(pm, w_full, weak_full), mask_loss_func.masked_ce(pml, w_low, weak_low)
+        else:
+            loss_mask, loss_mask_low = masked_ce(pm, w_full, weak_full), masked_ce(pml, w_low, weak_low)
         lst_hw = src_lst.shape[-2:]
         scaled = F.interpolate(pm.flatten(0, 1), lst_hw, mode="bilinear", align_corners=True).view(lr, b * nf, *lst_hw)
         region_scaled = F.interpolate(region, lst_hw, mode="nearest").flatten(0, 1)

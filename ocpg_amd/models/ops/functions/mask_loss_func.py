@@ -120,3 +120,33 @@ class DetLosses(Function):
 
 def det_losses(logits, boxes, src, valid, labels, tboxes, num_boxes, alpha, bad=None):
     return DetLosses.apply(logits, boxes, src, valid, labels, tboxes, num_boxes, alpha, bad)
+
+
+class MaskedCE(Function):
+    """mean over the clip of BCE-with-logits(sigmoid(x) * w, m * w) for all layers (csrc/masked_ce.hip) -> [Lr]."""
+
+    @staticmethod
+    def forward(ctx, x, w, t):
+        x, w, t = x.float().contiguous(), w.float().contiguous(), t.float().contiguous()
+        lr = x.shape[0]
+        per = x.numel() // lr
+        assert w.numel() == per and t.numel() == per and per % 4 == 0
+        part = torch.empty((lr, 512), dtype=torch.float32, device=x.device)
+        check(lib().ocpg_masked_ce_fwd_f32(x.data_ptr(), w.data_ptr(), t.data_ptr(), lr, per, part.data_ptr(), _st()), "ocpg_masked_ce_fwd_f32")
+        ctx.save_for_backward(x, w, t)
+        return part.sum(1) / per
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gloss):
+        x, w, t = ctx.saved_tensors
+        lr = x.shape[0]
+        gx = torch.empty_like(x)
+        check(lib().ocpg_masked_ce_bwd_f32(x.data_ptr(), w.data_ptr(), t.data_ptr(), gloss.float().contiguous().data_ptr(), lr, x.numel() // lr,
+                                           gx.data_ptr(), _st()), "ocpg_masked_ce_bwd_f32")
+        return gx, None, None
+
+
+def masked_ce(x, w, m):
+    """x [Lr,B,T,H,W] logits; w, m [B,T,H,W] weight map and weak mask (no gradient)."""
+    return MaskedCE.apply(x, w, m * w)
