@@ -34,6 +34,18 @@ def mask_key(mask):
     return getattr(mask, "_ocpg_key", None) if MEMO_ENABLED else None
 
 
+def fully_valid(key) -> bool:
+    """True when the mask a key describes has no padding at all (every image fills its map) -- known on the host."""
+    if key is None:
+        return False
+    if key[0] == "rect":
+        _, h, w, valid = key
+        return all(vh == h and vw == w for vh, vw in valid)
+    if key[0] == "resized":          # nearest resize of an all-False mask is all-False
+        return fully_valid(key[1])
+    return False
+
+
 def memo(tag, key, device, compute):
     """compute() (tensors without autograd history, never modified in place downstream), cached on (tag, key, device)."""
     if key is None:

@@ -38,14 +38,17 @@ def to_channels_last(model):
     return model
 
 
-def run_train_step(g, tag, device, rtol, atol, channels_last=False):
-    from ocpg_amd.util.misc import NestedTensor
+def run_train_step(g, tag, device, rtol, atol, channels_last=False, tag_masks=False):
+    from ocpg_amd.util.misc import NestedTensor, tag_rect_mask
     meta = g.meta
     args, model, crit = build_product(meta, device)
     if channels_last:
         to_channels_last(model)
     B, T, H, W = meta["B"], meta["T"], meta["H"], meta["W"]
     x, mask, targets = cases.e2e_inputs(B, T, H, W, meta[f"{tag}_sizes"], device)
+    if tag_masks:       # what the collate helpers do: declare every frame's valid extent (memoised mask-only tensors, and the
+        #                 "no padding anywhere" shortcut of the transformer when all frames fill the map)
+        tag_rect_mask(mask, [hw for hw in meta[f"{tag}_sizes"] for _ in range(T)])
     model.train(), crit.train()
     out = model(NestedTensor(x, mask), text_for(B, device), targets)
     losses, *_ = crit(out, targets)

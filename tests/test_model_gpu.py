@@ -67,6 +67,14 @@ def test_train_step_matches_reference(golden, dev, tag):
     print(res)
 
 
+@pytest.mark.parametrize("tag", ["nopad", "pad"])
+def test_train_step_with_tagged_masks(golden, dev, tag):
+    """Same reference vectors with the padding mask tagged by its host-known valid extents: memoised level masks / position
+    encodings / valid ratios / reference grid; for 'nopad' also the transformer's no-padding shortcut (masked_fill skipped)."""
+    model_checks.run_train_step(golden("e2e_tiny"), tag, dev, rtol=1e-3, atol=1e-4, tag_masks=True)
+    model_checks.run_train_step(golden("e2e_tiny"), tag, dev, rtol=1e-3, atol=1e-4, tag_masks=True)      # second run: cache hits
+
+
 def test_train_step_channels_last_layout(golden, dev):
     """The bench layout (channels-last convs: NHWC frozen-BN kernels, 1x1 convs as hipBLASLt GEMMs) against the same
     reference vectors, fp32, same bounds."""
