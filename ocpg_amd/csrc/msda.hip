@@ -349,8 +349,11 @@ struct __attribute__((aligned(16))) TileRec {
   int pad;
 };
 
+#ifndef MSDA_WPE
+#define MSDA_WPE 3      // waves per SIMD the register allocator is held to (152 VGPRs unconstrained = 3)
+#endif
 template <int G, int NB, bool GATHER = true>
-__global__ __launch_bounds__(256) void msda_bwd_tiled(const float* __restrict__ value, const int64_t* __restrict__ shapes,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MSDA_WPE, 8))) void msda_bwd_tiled(const float* __restrict__ value, const int64_t* __restrict__ shapes,
                                                       const int64_t* __restrict__ level_start, const float* __restrict__ loc,
                                                       const float* __restrict__ attn, const float* __restrict__ gout, int S, int M,
                                                       int P, TileGeom geo, float* __restrict__ gvalue, float* __restrict__ gloc,
@@ -697,7 +700,10 @@ __global__ __launch_bounds__(256) void msda_bwd_generic(const T* __restrict__ va
 // data-driven, so the margin only has to cover the SPREAD of the offsets, not their common shift.
 inline bool make_tile_geom(const int64_t* sh, int L, int D, int rows_per_pass, int P, TileGeom& g, size_t& lds_bytes) {
   const int margin = 3;
-  const size_t cap = 52 * 1024;                       // LDS budget per workgroup -> 3 workgroups (12 waves) per CU
+#ifndef MSDA_LDS_CAP_KB
+#define MSDA_LDS_CAP_KB 52
+#endif
+  const size_t cap = MSDA_LDS_CAP_KB * 1024;            // LDS budget per workgroup: 52 KB -> 3 workgroups (12 waves) per CU
   const size_t rec_bytes = (size_t)rows_per_pass * P * sizeof(TileRec);
   g.L = L;
   int base = 0;
