@@ -65,6 +65,7 @@ class FrozenBatchNorm2d(nn.Module):
 
 
 FUSED_CONV_BN = os.environ.get("OCPG_FUSED_CONV_BN", "1") != "0"     # A/B switch
+FUSED_CONV3X3_BN = os.environ.get("OCPG_FUSED_CONV3X3_BN", "0") != "0"     # opt-in: 3x3 conv + BN + ReLU as im2col + epilogue GEMM (small maps); measured neutral in the step
 
 
 def conv_bn_act(conv, bn, x, skip, relu):
@@ -77,6 +78,14 @@ def conv_bn_act(conv, bn, x, skip, relu):
             scale, shift = bn.scale_shift()
             n, _, h, wd = x.shape
             return conv_bn_func.conv1x1_bn_act(x, w, scale, shift, skip, relu, amp_cache._split_rows(n * h * wd) if amp_cache.SPLIT_K else 1)
+    if FUSED_CONV3X3_BN and skip is None and conv_bn_func.eligible3x3(x, conv):
+        w = amp_cache.lookup(conv.weight)
+        if w.dtype == x.dtype:
+            scale, shift = bn.scale_shift()
+            s = conv.stride[0]
+            rows = x.shape[0] * ((x.shape[2] - 1) // s + 1) * ((x.shape[3] - 1) // s + 1)
+            return conv_bn_func.conv3x3_bn_act(x, w, scale, shift, relu, s, conv.dilation[0],
+                                               amp_cache._split_rows(rows) if amp_cache.SPLIT_K else 1)
     return bn(conv(x), skip=skip, relu=relu)
 
 
@@ -96,7 +105,7 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         y = conv_bn_act(self.conv1, self.bn1, x, None, True)
-        y = self.bn2(self.conv2(y), relu=True)
+        y = conv_bn_act(self.conv2, self.bn2, y, None, True)
         skip = x if self.downsample is None else conv_bn_act(self.downsample[0], self.downsample[1], x, None, False)
         return conv_bn_act(self.conv3, self.bn3, y, skip, True)
 

@@ -98,3 +98,87 @@ class Conv1x1BNAct(Function):
 
 def conv1x1_bn_act(x, w, scale, shift, skip, relu, splits):
     return Conv1x1BNAct.apply(x, w, scale, shift, skip, relu, splits)
+
+
+# ---- 3x3 conv (padding == dilation, stride 1|2) + frozen BN + ReLU: im2col (HIP) -> GEMM with the BN/ReLU epilogue ---------
+_DT3 = {torch.float32: 0, torch.bfloat16: 1}
+
+
+def eligible3x3(x, conv):
+    """Where the patch-matrix GEMM beats MIOpen (tools/bench_conv3x3.py): >= 256 channels on maps of <= 12288 output pixels."""
+    if not (x.is_cuda and x.dim() == 4 and x.dtype in _DT3 and conv.kernel_size == (3, 3) and conv.groups == 1 and conv.bias is None
+            and conv.stride[0] == conv.stride[1] and conv.stride[0] in (1, 2) and conv.dilation[0] == conv.dilation[1]
+            and conv.padding == conv.dilation and conv.padding_mode == "zeros" and x.is_contiguous(memory_format=_CL)):
+        return False
+    s = conv.stride[0]
+    rows = x.shape[0] * ((x.shape[2] - 1) // s + 1) * ((x.shape[3] - 1) // s + 1)
+    return x.shape[1] >= 256 and (x.shape[1] * x.element_size()) % 16 == 0 and rows <= 12288
+
+
+class Conv3x3BNAct(Function):
+    @staticmethod
+    def forward(ctx, x, w, scale, shift, relu, stride, dil, splits):
+        n, c, h, wd = x.shape
+        co = w.shape[0]
+        ho, wo = (h - 1) // stride + 1, (wd - 1) // stride + 1
+        m = n * ho * wo
+        dt = _DT3[x.dtype]
+        L = lib()
+        st = torch.cuda.current_stream().cuda_stream
+        cols = torch.empty((m, 9 * c), dtype=x.dtype, device=x.device)
+        check(L.ocpg_im2col3x3_nhwc(x.data_ptr(), n, h, wd, c, stride, dil, cols.data_ptr(), dt, st), "ocpg_im2col3x3_nhwc")
+        w2 = w.permute(0, 2, 3, 1).reshape(co, 9 * c)             # a view when the weight is channels-last
+        if not w2.is_contiguous():
+            w2 = w2.contiguous()
+        y = torch.empty((n, co, ho, wo), dtype=x.dtype, device=x.device, memory_format=_CL)
+        rc = L.ocpg_gemm_bn_act(cols.data_ptr(), w2.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr(), None, int(relu), dt, m, co,
+                                9 * c, st) if EPILOGUE else -1105
+        if rc and rc != -1105:
+            check(rc, "ocpg_gemm_bn_act")
+        if rc:
+            check(L.ocpg_gemm(cols.data_ptr(), w2.data_ptr(), y.data_ptr(), None, dt, dt, 0, 1, m, co, 9 * c, 9 * c, 9 * c, co, 1, 0, 0, 0, 1.0,
+                              0.0, st), "ocpg_gemm")
+            check(L.ocpg_bn_act_fwd(y.data_ptr(), scale.data_ptr(), shift.data_ptr(), None, y.data_ptr(), m, co, 1, int(relu), dt, st),
+                  "ocpg_bn_act_fwd")
+        ctx.save_for_backward(cols, w2, y, scale)
+        ctx.meta = (bool(relu), splits, (n, c, h, wd, ho, wo, stride, dil), w.shape)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        cols, w2, y, scale = ctx.saved_tensors
+        relu, splits, (n, c, h, wd, ho, wo, stride, dil), wshape = ctx.meta
+        co = w2.shape[0]
+        m, k = cols.shape
+        dt = _DT3[y.dtype]
+        L = lib()
+        st = torch.cuda.current_stream().cuda_stream
+        if gy.dtype != y.dtype or not gy.is_contiguous(memory_format=_CL):
+            gy = gy.to(y.dtype).contiguous(memory_format=_CL)
+        gz = torch.empty_like(y)
+        check(L.ocpg_bn_act_bwd(gy.data_ptr(), y.data_ptr(), scale.data_ptr(), gz.data_ptr(), None, m, co, 1, int(relu), dt, st), "ocpg_bn_act_bwd")
+        gx = gw = None
+        if ctx.needs_input_grad[0]:     # dcols[m, 9c] = gz[m, co] w2[co, 9c] ; gx = col2im(dcols)
+            dcols = torch.empty((m, k), dtype=y.dtype, device=y.device)
+            check(L.ocpg_gemm(gz.data_ptr(), w2.data_ptr(), dcols.data_ptr(), None, dt, dt, 0, 0, m, k, co, co, k, k, 1, 0, 0, 0, 1.0, 0.0, st),
+                  "ocpg_gemm")
+            gx = torch.empty((n, c, h, wd), dtype=y.dtype, device=y.device, memory_format=_CL)
+            check(L.ocpg_col2im3x3_nhwc(dcols.data_ptr(), n, h, wd, c, stride, dil, gx.data_ptr(), dt, st), "ocpg_col2im3x3_nhwc")
+        if ctx.needs_input_grad[1]:     # gw[co, 9c] = gz^T cols, rows split
+            if splits > 1 and m % splits == 0:
+                r = m // splits
+                part = torch.empty((splits, co, k), dtype=y.dtype, device=y.device)
+                check(L.ocpg_gemm(gz.data_ptr(), cols.data_ptr(), part.data_ptr(), None, dt, dt, 1, 0, co, k, r, co, k, k, splits, r * co, r * k,
+                                  co * k, 1.0, 0.0, st), "ocpg_gemm")
+                g2 = part.sum(0)
+            else:
+                g2 = torch.empty((co, k), dtype=y.dtype, device=y.device)
+                check(L.ocpg_gemm(gz.data_ptr(), cols.data_ptr(), g2.data_ptr(), None, dt, dt, 1, 0, co, k, m, co, k, k, 1, 0, 0, 0, 1.0, 0.0, st),
+                      "ocpg_gemm")
+            gw = g2.view(co, 3, 3, c).permute(0, 3, 1, 2)          # channels-last strides of [co, c, 3, 3]
+        return gx, gw, None, None, None, None, None, None
+
+
+def conv3x3_bn_act(x, w, scale, shift, relu, stride, dil, splits):
+    return Conv3x3BNAct.apply(x, w, scale, shift, relu, int(stride), int(dil), splits)

@@ -331,6 +331,40 @@ def test_hip_mask_losses_equal_torch_formulas(dev, case):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("stride,dil", [(1, 1), (2, 1), (1, 2)])
+def test_conv3x3_bn_relu_fused_epilogue(dev, dtype, stride, dil):
+    """3x3 conv + frozen BN + ReLU as im2col (HIP) + one GEMM with the BN/ReLU epilogue (the path taken for >= 256 channels on
+    small maps) against MIOpen conv + the bn_act kernel: output, input gradient, weight gradient."""
+    from ocpg_amd.models import amp_cache, backbone
+    torch.manual_seed(1)
+    conv = amp_cache.Conv2d(256, 64, 3, stride=stride, padding=dil, dilation=dil, bias=False).to(dev)
+    conv.to(memory_format=torch.channels_last)
+    bn = backbone.FrozenBatchNorm2d(64).to(dev)
+    bn.weight.uniform_(0.5, 1.5), bn.bias.normal_(0, 0.1), bn.running_mean.normal_(0, 0.1), bn.running_var.uniform_(0.5, 1.5)
+    conv, bn = conv.to(dtype), bn.to(dtype)
+    x = torch.randn(3, 256, 13, 18, device=dev, dtype=dtype).contiguous(memory_format=torch.channels_last)
+    res = []
+    for fused in (True, False):
+        backbone.FUSED_CONV3X3_BN = fused
+        try:
+            xi = x.clone().requires_grad_(True)
+            conv.zero_grad()
+            y = backbone.conv_bn_act(conv, bn, xi, None, True)
+            assert (type(y.grad_fn).__name__ == "Conv3x3BNActBackward") == fused
+            go = torch.randn(y.shape, device=dev, dtype=dtype, generator=torch.Generator(device=dev).manual_seed(2))
+            y.backward(go)
+            res.append([y.detach().float(), xi.grad.float(), conv.weight.grad.float()])
+        finally:
+            backbone.FUSED_CONV3X3_BN = False       # the module default (opt-in path)
+    for a, b_ in zip(*res):
+        assert a.shape == b_.shape
+        if dtype == torch.float32:
+            assert (a - b_).abs().max().item() <= 5e-5 * b_.abs().max().item() + 1e-6
+        else:       # bf16: ReLU flips at pre-activations within an ulp of zero (see test_bottleneck_fused_conv_bn_act)
+            assert (a - b_).norm().item() <= 5e-2 * b_.norm().item()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("project", [False, True])
 def test_bottleneck_fused_conv_bn_act(dev, dtype, project):
     """Bottleneck with the fused 1x1-conv + frozen-BN (+ skip) + ReLU nodes (plan-cached hipBLASLt GEMM + bn_act in place)
