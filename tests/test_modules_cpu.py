@@ -74,3 +74,27 @@ def test_inverse_sigmoid_matches_reference_formula():
     ref_e = torch.log(ends.clamp(0, 1).clamp(min=1e-5) / (1 - ends.clamp(0, 1)).clamp(min=1e-5))
     assert (inverse_sigmoid(ends) - ref_e).abs().max() <= 1.5e-3           # saturated ends only (see the docstring)
     assert (inverse_sigmoid(ends).sigmoid() - ref_e.sigmoid()).abs().max() <= 2e-8
+
+
+def test_row_split_and_layout_helpers():
+    """Host logic behind the GEMM-shaped gradients and the fused casts: the row-split divisor rule, the gradient/parameter
+    layout test that routes a gradient to the one-launch cast, and the no-padding predicate of a tagged mask."""
+    from ocpg_amd.models import amp_cache
+    from ocpg_amd.util import misc
+    for m in (2400, 9600, 38400, 51000, 153600, 4097, 12345, 8191, 100003):
+        s = amp_cache._split_rows(m)
+        assert s >= 1 and m % s == 0
+        if s > 1:
+            assert 768 <= m // s <= 3072
+    assert amp_cache._split_rows(2400) == 1 and amp_cache._split_rows(9600) > 1
+    gy, x = torch.randn(9600, 24), torch.randn(9600, 40)
+    assert torch.allclose(amp_cache.weight_grad(gy, x), gy.t() @ x, rtol=1e-4, atol=1e-3)
+    w = torch.empty(64, 32, 1, 1).to(memory_format=torch.channels_last)
+    assert amp_cache._same_layout(torch.empty(64, 32, 1, 1), w.shape, w.stride())              # 1x1: same memory order
+    w3 = torch.empty(64, 32, 3, 3).to(memory_format=torch.channels_last)
+    assert not amp_cache._same_layout(torch.empty(64, 32, 3, 3), w3.shape, w3.stride())         # 3x3 NCHW grad vs NHWC weight
+    assert amp_cache._same_layout(torch.empty(64, 32, 3, 3).to(memory_format=torch.channels_last), w3.shape, w3.stride())
+    assert amp_cache._dense(w3) and amp_cache._dense(torch.empty(5, 7)) and not amp_cache._dense(torch.empty(5, 8)[:, ::2])
+    full = ("rect", 64, 96, ((64, 96),) * 4)
+    assert misc.fully_valid(full) and misc.fully_valid(("resized", full, (8, 12)))
+    assert not misc.fully_valid(("rect", 64, 96, ((64, 96), (60, 96)))) and not misc.fully_valid(None)
