@@ -3,10 +3,14 @@
 Under autocast every Conv2d / Linear casts its fp32 weight (and bias) to bf16/fp16 with its own kernel and its own
 autograd node, and the backward casts every weight gradient back with another kernel: ~200 + ~200 launches per step for
 ResNet-101 + the transformer -- on MI355X the training step is host/launch-bound, so they matter.
-Here the model casts ALL such parameters once per forward with a multi-tensor copy (`FusedCast`, one autograd node whose
-backward is one multi-tensor copy of the gradients back to fp32), and the layers below pick the low-precision copies up
-through `lookup`.  Outside autocast nothing changes (the table is empty and `lookup` returns the parameter itself).
-Numerically identical to autocast's own per-op casts.
+Here the model casts ALL such parameters once per forward with ONE launch (`FusedCast`: csrc/multi_cast.hip writes every
+working copy into a persistent flat buffer; the backward casts every gradient back with one launch), and the layers below
+pick the low-precision copies up through `lookup`.  Outside autocast nothing changes (the table is empty and `lookup`
+returns the parameter itself).  Numerically identical to autocast's own per-op casts.
+
+The module also hosts the GEMM-shaped layer variants that ride on those copies: 1x1 convolutions of channels-last maps as
+hipBLASLt GEMMs, weight gradients over many rows as row-split batched GEMMs (`weight_grad`), and `linear` for token
+matrices.
 """
 import contextlib
 import os
