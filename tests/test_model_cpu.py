@@ -26,3 +26,42 @@ def test_train_step_matches_reference(golden, msda_double, tag):
 @pytest.mark.parametrize("tag", ["nopad", "pad"])
 def test_eval_tail_matches_reference(golden, msda_double, tag):
     model_checks.run_eval(golden("e2e_tiny"), tag, torch.device("cpu"), rtol=2e-4, atol=2e-5)
+
+
+def test_checkpoint_wire_format(tmp_path):
+    """util/checkpoint.py: the reference's checkpoint dict round-trips (legacy serialization, strict=False resume that keeps the
+    current learning rates and drops gamma / milestones), and the fine-tuning filter drops exactly the class heads."""
+    import argparse
+    import pickle
+    import cases
+    from ocpg_amd.models import build_model
+    from ocpg_amd.util import checkpoint as ck
+    args = cases.default_args(device="cpu", **cases.TINY)
+    torch.manual_seed(0)
+    model, _, _ = build_model(args)
+    opt = torch.optim.AdamW([{"params": [p for p in model.parameters() if p.requires_grad], "lr": 1e-4}], weight_decay=5e-4)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, [3, 5])
+    for p in model.parameters():
+        if p.requires_grad:
+            p.grad = torch.ones_like(p) * 1e-3
+    opt.step(), sched.step()
+    path = tmp_path / "checkpoint0000.pth"
+    ck.save_checkpoint(path, model, opt, sched, 0, argparse.Namespace(**vars(args)), grad_scaler=torch.amp.GradScaler("cpu", enabled=False))
+    with open(path, "rb") as f:
+        assert f.read(2) != b"PK"                      # legacy (non-zip) container, as the reference writes it
+    state = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(state) == {"model", "optimizer", "lr_scheduler", "epoch", "args", "grad_scaler"}
+    torch.manual_seed(1)
+    model2, _, _ = build_model(args)
+    opt2 = torch.optim.AdamW([{"params": [p for p in model2.parameters() if p.requires_grad], "lr": 5e-5}], weight_decay=5e-4)
+    sched2 = torch.optim.lr_scheduler.MultiStepLR(opt2, [2])
+    state["model"]["backbone.0.body.total_ops"] = torch.zeros(1)       # profiler residue some released checkpoints carry
+    missing, unexpected, epoch = ck.load_checkpoint(state, model2, opt2, sched2)
+    assert not missing and not unexpected and epoch == 0
+    for (k, a), (_, b) in zip(model.state_dict().items(), model2.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert opt2.param_groups[0]["lr"] == 5e-5                                       # the current run's learning rate wins
+    assert list(sched2.milestones) == [2] and sched2.last_epoch == sched.last_epoch   # milestones of THIS run, progress restored
+    kept = ck.pre_trained_model_to_finetune(state, args)
+    dropped = set(state["model"]) - set(kept)
+    assert dropped == {f"class_embed.{l}.{n}" for l in range(args.dec_layers) for n in ("weight", "bias")}
