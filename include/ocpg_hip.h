@@ -131,7 +131,7 @@ int ocpg_gemm_bn_act(const void* A, const void* W, void* D, const float* scale, 
  * models/segmentation.py:203-211,253-315 as called from models/criterion.py:141-178).
  *
  * Level-set loss: x [Lr,N,h,w] logits, feats [N,CF,h,w] (first C channels used, C <= 16), box [N,h,w] in {0,1}.
- *   fwd: sums [Lr,N,7+2C] and coef [Lr,N,8+2C] are scratch the backward re-reads; loss [Lr].
+ *   fwd: sums [Lr,N,ceil(h*w/1024),7+2C] scratch (per-workgroup partials), coef [Lr,N,8+2C] kept for the backward; loss [Lr].
  *   bwd: gloss [Lr] upstream gradient -> gx [Lr,N,h,w], gfeat [N,CF,h,w] (may be NULL), both fully written. */
 int ocpg_levelset_fwd_f32(const float* x, const float* feats, const float* box, int Lr, int N, int C, int CF, int h, int w, float* sums,
                           float* coef, float* loss, void* stream);

@@ -19,7 +19,8 @@
 //   dlen/dw_p = sgn(w_p - w_up) - sgn(w_down - w_p) + sgn(w_p - w_left) - sgn(w_right - w_p)   (terms that exist)
 //   dx = (dfg - dbg) p (1 - p) box;   dfeats_c = box sum_l dt_c
 //
-// levelset_sums: one lane per pixel, 2C+7 partial sums per (layer, frame) reduced wave -> block -> one atomic per sum.
+// levelset_sums: one lane per pixel, 2C+7 partial sums per (layer, frame) reduced wave -> block -> one plain store per sum into
+// the workgroup's partial row; levelset_final reduces the rows (240 workgroups adding into the same 29 addresses serialise).
 // HBM-bound streaming passes: (Lr + C + 1) floats in per pixel forward; backward the same in, (Lr + CF) out.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -30,6 +31,7 @@ namespace {
 
 constexpr int CMAX = 16;                 // level-set feature channels used (the reference uses 11)
 constexpr float EPS_W = 0.00001f;        // clamp of the region mass (segmentation.py:286-287)
+constexpr int PPT = 4;                   // pixels per lane in levelset_sums
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 __device__ __forceinline__ float sgnf_(float v) { return (v > 0.f) - (v < 0.f); }
@@ -46,14 +48,16 @@ __global__ __launch_bounds__(256) void levelset_sums(const float* __restrict__ x
                                                      float* __restrict__ sums) {
   const int hw = h * w;
   const int n = blockIdx.y, l = blockIdx.z;
-  const int px = blockIdx.x * 256 + threadIdx.x;
   const int NS = 7 + 2 * C;
   float acc[7 + 2 * CMAX];
 #pragma unroll
   for (int i = 0; i < 7 + 2 * CMAX; ++i) acc[i] = 0.f;
-  if (px < hw) {
-    const float* xl = x + ((long long)l * N + n) * hw;
-    const float* bx = box + (long long)n * hw;
+  const float* xl = x + ((long long)l * N + n) * hw;
+  const float* bx = box + (long long)n * hw;
+#pragma unroll 1
+  for (int it = 0; it < PPT; ++it) {               // PPT pixels per lane: the 29-value workgroup reduction is paid once per 1024 pixels
+    const int px = blockIdx.x * (256 * PPT) + it * 256 + threadIdx.x;
+    if (px >= hw) break;
     const float b = bx[px];
     const float p = sigmoidf_(xl[px]);
     const float fg = p * b, bg = (1.f - p) * b;
@@ -68,7 +72,7 @@ __global__ __launch_bounds__(256) void levelset_sums(const float* __restrict__ x
       acc[4] += fabsf(pr * br - fg);
       acc[5] += fabsf((1.f - pr) * br - bg);
     }
-    acc[6] = b;
+    acc[6] += b;
     if (b != 0.f) {
       const float* f = feats + (long long)n * CF * hw + px;
       float t2 = 0.f;
@@ -77,11 +81,11 @@ __global__ __launch_bounds__(256) void levelset_sums(const float* __restrict__ x
         if (c < C) {
           const float t = f[(long long)c * hw] * b;
           t2 += t * t;
-          acc[7 + c] = fg * t;
-          acc[7 + CMAX + c] = bg * t;
+          acc[7 + c] += fg * t;
+          acc[7 + CMAX + c] += bg * t;
         }
       }
-      acc[0] = fg; acc[1] = bg; acc[2] = fg * t2; acc[3] = bg * t2;
+      acc[0] += fg; acc[1] += bg; acc[2] += fg * t2; acc[3] += bg * t2;
     }
   }
   __shared__ float red[4][7 + 2 * CMAX];
@@ -101,47 +105,52 @@ __global__ __launch_bounds__(256) void levelset_sums(const float* __restrict__ x
     if (used) {
       const float v = red[0][i] + red[1][i] + red[2][i] + red[3][i];
       const int slot = i < 7 ? i : (i < 7 + CMAX ? 7 + (i - 7) : 7 + C + (i - 7 - CMAX));
-      atomicAdd(sums + ((long long)l * N + n) * NS + slot, v);
+      // per-workgroup partial (plain store): part [Lr, N, gridDim.x, NS]; levelset_final reduces them
+      sums[(((long long)l * N + n) * gridDim.x + blockIdx.x) * NS + slot] = v;
     }
   }
 }
 
 // coef layout per (l, n): [0] k1_fg [1] k2_fg [2] k1_bg [3] k2_bg [4] (2-r)_fg [5] (2-r)_bg [6] 1/(C pixels) [7] 1e-5/pixels
 //                         [8..8+C) c_fg [8+C..8+2C) c_bg
-__global__ __launch_bounds__(64) void levelset_final(const float* __restrict__ sums, int Lr, int N, int C, float* __restrict__ coef,
+__global__ __launch_bounds__(64) void levelset_final(const float* __restrict__ part, int nblk, int N, int C, float* __restrict__ coef,
                                                      float* __restrict__ loss) {
-  const int l = blockIdx.x;
+  __shared__ float s[7 + 2 * CMAX];
+  const int n = blockIdx.x, l = blockIdx.y;
   const int NS = 7 + 2 * C, NC = 8 + 2 * C;
-  float part = 0.f;
-  for (int n = threadIdx.x; n < N; n += 64) {
-    const float* s = sums + ((long long)l * N + n) * NS;
-    float* k = coef + ((long long)l * N + n) * NC;
-    const float pixels = fmaxf(s[6], 1.f);
-    float e_tot = 0.f;
-#pragma unroll
-    for (int side = 0; side < 2; ++side) {
-      const float W = s[side], A = s[2 + side];
-      const float D = fmaxf(W, EPS_W);
-      const float r = W / D, delta = W > EPS_W ? 1.f : 0.f;
-      float cs = 0.f, cc = 0.f;
-      for (int c = 0; c < C; ++c) {
-        const float S = s[7 + side * C + c];
-        const float cv = S / D;
-        k[8 + side * C + c] = cv;
-        cs += cv * S;
-        cc += cv * cv;
-      }
-      e_tot += A - 2.f * cs + cc * W;
-      k[2 * side] = 4.f - 2.f * r;
-      k[2 * side + 1] = (1.f + 2.f * delta - 2.f * r * delta) * cc;
-      k[4 + side] = 2.f - r;
-    }
-    k[6] = 1.f / ((float)C * pixels);
-    k[7] = 0.00001f / pixels;
-    part += e_tot / (float)C / pixels + 0.00001f * (s[4] + s[5]) / pixels;
+  const float* p = part + ((long long)l * N + n) * nblk * NS;
+  for (int slot = 0; slot < NS; ++slot) {            // reduce the workgroup partials of this (layer, frame)
+    float v = 0.f;
+    for (int b = threadIdx.x; b < nblk; b += 64) v += p[(long long)b * NS + slot];
+    v = wave_sum(v);
+    if (threadIdx.x == 0) s[slot] = v;
   }
-  part = wave_sum(part);
-  if (threadIdx.x == 0) loss[l] = part / (float)N;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  float* k = coef + ((long long)l * N + n) * NC;
+  const float pixels = fmaxf(s[6], 1.f);
+  float e_tot = 0.f;
+#pragma unroll
+  for (int side = 0; side < 2; ++side) {
+    const float W = s[side], A = s[2 + side];
+    const float D = fmaxf(W, EPS_W);
+    const float r = W / D, delta = W > EPS_W ? 1.f : 0.f;
+    float cs = 0.f, cc = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float S = s[7 + side * C + c];
+      const float cv = S / D;
+      k[8 + side * C + c] = cv;
+      cs += cv * S;
+      cc += cv * cv;
+    }
+    e_tot += A - 2.f * cs + cc * W;
+    k[2 * side] = 4.f - 2.f * r;
+    k[2 * side + 1] = (1.f + 2.f * delta - 2.f * r * delta) * cc;
+    k[4 + side] = 2.f - r;
+  }
+  k[6] = 1.f / ((float)C * pixels);
+  k[7] = 0.00001f / pixels;
+  atomicAdd(loss + l, (e_tot / (float)C / pixels + 0.00001f * (s[4] + s[5]) / pixels) / (float)N);      // N adds per address
 }
 
 __global__ __launch_bounds__(256) void levelset_bwd(const float* __restrict__ x, const float* __restrict__ feats,
@@ -218,10 +227,11 @@ int ocpg_levelset_fwd_f32(const float* x, const float* feats, const float* box, 
   if (!sums || !coef || !loss) return -1010;
   hipStream_t st = (hipStream_t)stream;
   const int hw = h * w;
-  hipError_t e = hipMemsetAsync(sums, 0, sizeof(float) * (size_t)Lr * N * (7 + 2 * C), st);
+  const int nblk = (hw + 256 * PPT - 1) / (256 * PPT);
+  hipError_t e = hipMemsetAsync(loss, 0, sizeof(float) * (size_t)Lr, st);
   if (e != hipSuccess) return -(int)e;
-  levelset_sums<<<dim3((hw + 255) / 256, N, Lr), 256, 0, st>>>(x, feats, box, N, C, CF, h, w, sums);
-  levelset_final<<<Lr, 64, 0, st>>>(sums, Lr, N, C, coef, loss);
+  levelset_sums<<<dim3(nblk, N, Lr), 256, 0, st>>>(x, feats, box, N, C, CF, h, w, sums);
+  levelset_final<<<dim3(N, Lr), 64, 0, st>>>(sums, nblk, N, C, coef, loss);
   e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }

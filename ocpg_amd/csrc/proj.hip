@@ -37,21 +37,37 @@ __device__ __forceinline__ float wave_max_all(float v) {
   return v;
 }
 
-// colstat [F, 3, W]: max, tie count, mean
+// colstat [F, 3, W]: max, tie count, mean.  A workgroup owns 64 columns of a frame; its 4 waves walk interleaved rows
+// (coalesced 256-B row segments) and merge their (max, ties, sum) through LDS: 4x the lanes in flight of one lane per column.
 __global__ __launch_bounds__(256) void proj_col_stats(const float* __restrict__ x, int H, int W, float* __restrict__ colstat) {
+  __shared__ float sm[3][4][64];
   const int f = blockIdx.y;
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= W) return;
-  const float* xf = x + (long long)f * H * W + col;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
   float mx = -1.f, cnt = 0.f, sum = 0.f;
-  for (int y = 0; y < H; ++y) {
-    const float p = sigmoidf_(xf[(long long)y * W]);
-    sum += p;
-    if (p > mx) { mx = p; cnt = 1.f; }
-    else if (p == mx) cnt += 1.f;
+  if (col < W) {
+    const float* xf = x + (long long)f * H * W + col;
+    for (int y = wave; y < H; y += 4) {
+      const float p = sigmoidf_(xf[(long long)y * W]);
+      sum += p;
+      if (p > mx) { mx = p; cnt = 1.f; }
+      else if (p == mx) cnt += 1.f;
+    }
   }
-  float* o = colstat + (long long)f * 3 * W + col;
-  o[0] = mx; o[W] = cnt; o[2 * W] = sum / (float)H;
+  sm[0][wave][lane] = mx; sm[1][wave][lane] = cnt; sm[2][wave][lane] = sum;
+  __syncthreads();
+  if (wave == 0 && col < W) {
+    float m = sm[0][0][lane], c = sm[1][0][lane], s_ = sm[2][0][lane];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      const float mk = sm[0][k][lane], ck = sm[1][k][lane];
+      if (mk > m) { m = mk; c = ck; }
+      else if (mk == m) c += ck;
+      s_ += sm[2][k][lane];
+    }
+    float* o = colstat + (long long)f * 3 * W + col;
+    o[0] = m; o[W] = c; o[2 * W] = s_ / (float)H;
+  }
 }
 
 // rowstat [F, 3, H]: one wave per row
@@ -196,7 +212,7 @@ int ocpg_proj_fwd_f32(const float* x, const float* tcmax, const float* trmax, co
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(loss, 0, sizeof(float) * Lr, st);
   if (e != hipSuccess) return -(int)e;
-  proj_col_stats<<<dim3((W + 255) / 256, (unsigned)F), 256, 0, st>>>(x, H, W, colstat);
+  proj_col_stats<<<dim3((W + 63) / 64, (unsigned)F), 256, 0, st>>>(x, H, W, colstat);
   proj_row_stats<<<(unsigned)((F * H + 3) / 4), 256, 0, st>>>(x, (int)F, H, W, rowstat);
   proj_dice<<<dim3(B, Lr), 256, 0, st>>>(colstat, rowstat, tcmax, trmax, tcmean, trmean, B, T, H, W, IU, loss);
   e = hipGetLastError();

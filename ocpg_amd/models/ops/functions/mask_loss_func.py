@@ -19,7 +19,7 @@ class LevelSetLoss(Function):
         lr, n, h, w = x.shape
         cf = feats.shape[1]
         assert feats.shape == (n, cf, h, w) and box.shape == (n, h, w) and 0 < C <= cf
-        sums = torch.empty((lr, n, 7 + 2 * C), dtype=torch.float32, device=x.device)
+        sums = torch.empty((lr, n, (h * w + 1023) // 1024, 7 + 2 * C), dtype=torch.float32, device=x.device)
         coef = torch.empty((lr, n, 8 + 2 * C), dtype=torch.float32, device=x.device)
         loss = torch.empty((lr,), dtype=torch.float32, device=x.device)
         check(lib().ocpg_levelset_fwd_f32(x.data_ptr(), feats.data_ptr(), box.data_ptr(), lr, n, C, cf, h, w, sums.data_ptr(),
