@@ -65,3 +65,31 @@ def test_checkpoint_wire_format(tmp_path):
     kept = ck.pre_trained_model_to_finetune(state, args)
     dropped = set(state["model"]) - set(kept)
     assert dropped == {f"class_embed.{l}.{n}" for l in range(args.dec_layers) for n in ("weight", "bias")}
+
+
+def test_engine_train_step(golden, msda_double):
+    """engine.train_step == the reference iteration: total loss of the golden fixture, clipped gradient norm <= max_norm, the
+    parameters move, and the NaN-term substitution (engine.py:53-59) yields a graph-carrying zero."""
+    import cases
+    from ocpg_amd import engine
+    from ocpg_amd.util.misc import NestedTensor
+    g = golden("e2e_tiny")
+    meta = g.meta
+    args, model, crit = model_checks.build_product(meta, torch.device("cpu"))
+    B, T, H, W = meta["B"], meta["T"], meta["H"], meta["W"]
+    x, mask, targets = cases.e2e_inputs(B, T, H, W, meta["nopad_sizes"], "cpu")
+    model.train(), crit.train()
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=5e-4)
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    loss, loss_dict, norm = engine.train_step(model, crit, NestedTensor(x, mask), model_checks.text_for(B, "cpu"), targets, opt, max_norm=0.1)
+    assert abs(loss - g["nopad_total"].item()) <= 2e-3 * abs(g["nopad_total"].item())
+    assert float(norm) > 0.1            # the returned value is the norm BEFORE clipping (clip_grad_norm_'s contract)
+    clipped = engine.total_grad_norm([p for p in model.parameters() if p.requires_grad])
+    assert float(clipped) <= 0.1 * (1 + 1e-4)
+    moved = sum(int(not torch.equal(v, before[k])) for k, v in model.state_dict().items())
+    assert moved > 100
+    a = torch.tensor(1.5, requires_grad=True)
+    fixed = engine.substitute_nan_terms({"x": a * 2, "y": a * float("nan")})
+    assert float(fixed["y"].detach()) == 0.0 and fixed["y"].requires_grad and float(fixed["x"].detach()) == 3.0
+    same = {"x": a * 2}
+    assert engine.substitute_nan_terms(same) is same
