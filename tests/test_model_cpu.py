@@ -93,3 +93,31 @@ def test_engine_train_step(golden, msda_double):
     assert float(fixed["y"].detach()) == 0.0 and fixed["y"].requires_grad and float(fixed["x"].detach()) == 3.0
     same = {"x": a * 2}
     assert engine.substitute_nan_terms(same) is same
+
+
+def test_video_inference_loop(golden, msda_double):
+    """inference.segment_video: clip chopping + best-query selection + un-pad / resize / sigmoid (inference_davis.py:196-250);
+    one clip covering the video == the model's own eval output post-processed by hand; merge_objects == the argmax rule."""
+    import torch.nn.functional as F
+    from ocpg_amd import inference
+    meta = golden("e2e_tiny").meta
+    args, model, _ = model_checks.build_product(meta, torch.device("cpu"), dataset_file="davis")
+    T, H, W = 3, meta["H"], meta["W"]
+    torch.manual_seed(0)
+    frames = torch.randn(T, 3, H, W)
+    text = model_checks.text_for(1, "cpu")
+    logits, masks = inference.segment_video(model, frames, text, clip_len=36, origin_size=(50, 70))
+    assert logits.shape[0] == T and masks.shape == (T, 50, 70) and float(masks.min()) >= 0 and float(masks.max()) <= 1
+    model.eval()
+    with torch.no_grad():
+        out = model([frames], text, [{"size": torch.tensor([H, W])}])
+    best = out["pred_logits"][0].sigmoid().mean(0).max(-1)[0].argmax()
+    want = F.interpolate(out["pred_masks"][0][:, best][None][:, :, :H, :W], size=(50, 70), mode="bilinear", align_corners=False).sigmoid()[0]
+    assert torch.allclose(masks, want, atol=1e-6)
+    l2, m2 = inference.segment_video(model, frames, text, clip_len=2)              # two clips: 2 + 1 frames
+    assert m2.shape == (T, H, W) and l2.shape[0] == T
+    objs = torch.stack([masks, 1 - masks])
+    lab = inference.merge_objects(objs)
+    assert lab.dtype == torch.uint8 and lab.shape == (T, 50, 70)
+    ref = torch.cat([torch.full((1, T, 50, 70), 0.1), torch.where(objs < 0.3, torch.zeros_like(objs), objs)], 0).argmax(0)
+    assert torch.equal(lab.long(), ref)
