@@ -35,11 +35,16 @@
 extern "C" {
 #endif
 
-/* replaces ms_deform_attn_forward (ms_deform_attn.h:20-39 -> ms_deform_attn_cuda.cu:20-80), float32 */
+/* replaces ms_deform_attn_forward (ms_deform_attn.h:20-39 -> ms_deform_attn_cuda.cu:20-80), float32.
+ * shapes_host: optional HOST copy of `shapes` (may be NULL).  When given, Lq == S (self-attention over the value's
+ * own pixels, the encoder case: query q IS pixel q) and level_start is the exclusive prefix sum of H_l*W_l, the
+ * column-tile kernels (LDS-staged sampling windows) are selected; results are identical either way up to fp32
+ * summation order.  The host copy is what the reference's module already owns: ms_deform_attn.py:94 asserts on the
+ * same tensor, which reads it back to the host on every call. */
 int ocpg_msda_fwd_f32(const float* value, const int64_t* shapes, const int64_t* level_start,
                       const float* loc, const float* attn,
                       int N, int S, int M, int D, int L, int Lq, int P,
-                      float* out, void* stream);
+                      float* out, const int64_t* shapes_host, void* stream);
 /* float64 variant (AT_DISPATCH_FLOATING_TYPES, ms_deform_attn_cuda.cu:64); used by the test.py protocol */
 int ocpg_msda_fwd_f64(const double* value, const int64_t* shapes, const int64_t* level_start,
                       const double* loc, const double* attn,
@@ -47,9 +52,8 @@ int ocpg_msda_fwd_f64(const double* value, const int64_t* shapes, const int64_t*
                       double* out, void* stream);
 
 /* replaces ms_deform_attn_backward (ms_deform_attn.h:41-61 -> ms_deform_attn_cuda.cu:83-152), float32.
- * shapes_host: optional HOST copy of `shapes` (may be NULL).  When given and Lq == S (self-attention over
- * the value's own pixels, the encoder case) the LDS-privatised tile kernel can be selected; results are
- * identical either way up to fp32 summation order. */
+ * shapes_host: as for the forward (may be NULL): selects the column-tile backward (gather kernel for grad_loc /
+ * grad_attn + bin-and-sum scatter kernel for grad_value) when Lq == S. */
 int ocpg_msda_bwd_f32(const float* value, const int64_t* shapes, const int64_t* level_start,
                       const float* loc, const float* attn, const float* grad_out,
                       int N, int S, int M, int D, int L, int Lq, int P,

@@ -18,7 +18,7 @@ _int = ctypes.c_int
 
 # symbol -> argtypes; must list every entry point declared in include/ocpg_hip.h
 SIGNATURES = {
-    "ocpg_msda_fwd_f32": [_vp, _i64p, _i64p, _vp, _vp] + [_int] * 7 + [_vp, _vp],
+    "ocpg_msda_fwd_f32": [_vp, _i64p, _i64p, _vp, _vp] + [_int] * 7 + [_vp, _vp, _vp],
     "ocpg_msda_fwd_f64": [_vp, _i64p, _i64p, _vp, _vp] + [_int] * 7 + [_vp, _vp],
     "ocpg_msda_bwd_f32": [_vp, _i64p, _i64p, _vp, _vp, _vp] + [_int] * 7 + [_vp, _vp, _vp, _vp, _vp],
     "ocpg_msda_bwd_f64": [_vp, _i64p, _i64p, _vp, _vp, _vp] + [_int] * 7 + [_vp, _vp, _vp, _vp],

@@ -23,7 +23,11 @@
 
 #include <algorithm>
 
+#include <cstdlib>
+
 #include "../../include/ocpg_hip.h"
+#include "msda_col.h"
+#include "msda_dev.h"
 
 namespace {
 
@@ -61,7 +65,9 @@ __device__ __forceinline__ void make_sample(T x_n, T y_n, T a, int H, int W, int
   }
 }
 
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+using ocpg_dev::ld4;
+using ocpg_dev::group_sum;
+using ocpg_dev::reduce_scatter_g8_p4;
 
 // ------------------------------------------------------------------------------------------------------
 // Fast forward: D = 4*G, G in {1,2,4,8,16,32,64}.  256 threads = 256/G rows per block.
@@ -175,13 +181,127 @@ __global__ __launch_bounds__(256) void msda_fwd_generic(const T* __restrict__ va
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Gather side of the backward (grad_loc, grad_attn; cuh:87-159 without the col2im scatter): row kernel, used with the
+// column-tile scatter kernel (msda_col.hip).  Differences from msda_bwd_fast<G, false>:
+//   * validity is folded into the per-axis weights (hy' = y0 >= 0 ? 1-ly : 0 ...) and the corner addresses are clamped
+//     into the map, so the inner loop has no masks and no selects: 4 unconditional 16-B loads, packed FMAs;
+//   * 4 samples are reduced together by a DPP reduce-scatter (12 moves) instead of 9 LDS-crossbar shuffles per sample.
+struct __attribute__((aligned(16))) GatherRec {
+  int pk;          // element offset of corner (ya, xa) relative to value[b, 0, m, 0]  |  iy1<<3 | iy0<<2 | ix1<<1 | ix0
+  int rowstride;   // W * M * D
+  float aW, aH;    // attention weight * level width / height (grad_loc scaling)
+  float hy, ly, hx, lx;   // masked by validity
+};
+
 template <int G>
-__device__ __forceinline__ float group_sum(float v) {
+__global__ __launch_bounds__(256) void msda_bwd_gather_row(const float* __restrict__ value, const int64_t* __restrict__ shapes,
+                                                           const int64_t* __restrict__ level_start, const float* __restrict__ loc,
+                                                           const float* __restrict__ attn, const float* __restrict__ gout, int S, int M,
+                                                           int L, int Lq, int P, long long rows, float* __restrict__ gloc,
+                                                           float* __restrict__ gattn) {
+  constexpr int D = 4 * G;
+  constexpr int ROWS = 256 / G;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  GatherRec* recs = reinterpret_cast<GatherRec*>(smem);
+  __shared__ int lvlH[kMaxLevels], lvlW[kMaxLevels], lvlS[kMaxLevels];
+  const int tid = threadIdx.x;
+  if (tid < L) {
+    lvlH[tid] = (int)shapes[2 * tid];
+    lvlW[tid] = (int)shapes[2 * tid + 1];
+    lvlS[tid] = (int)level_start[tid];
+  }
+  __syncthreads();
+  const int NS = L * P;
+  const int MD = M * D;
+  const int r = tid / G, j = tid % G;
+  const long long qrow = (long long)(blockIdx.x / M) * ROWS + r;          // head fastest: one head per XCD L2 (see msda_fwd_fast)
+  const long long row = qrow * M + (blockIdx.x % M);
+  const bool live = qrow * M < rows;
+  if (live) {
+    const float* lrow = loc + row * NS * 2;
+    const float* arow = attn + row * NS;
+    for (int s = j; s < NS; s += G) {
+      const int l = s / P;
+      const int H = lvlH[l], W = lvlW[l];
+      GatherRec rec;
+      const float h_im = lrow[2 * s + 1] * (float)H - 0.5f, w_im = lrow[2 * s] * (float)W - 0.5f;
+      const float a = arow[s];
+      rec.rowstride = W * MD;
+      if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+        const int y0 = (int)floorf(h_im), x0 = (int)floorf(w_im);
+        const float ly = h_im - (float)y0, lx = w_im - (float)x0;
+        const bool iy0 = y0 >= 0, iy1 = y0 + 1 <= H - 1, ix0 = x0 >= 0, ix1 = x0 + 1 <= W - 1;
+        rec.hy = iy0 ? 1.f - ly : 0.f;
+        rec.ly = iy1 ? ly : 0.f;
+        rec.hx = ix0 ? 1.f - lx : 0.f;
+        rec.lx = ix1 ? lx : 0.f;
+        rec.aW = a * (float)W;
+        rec.aH = a * (float)H;
+        rec.pk = ((lvlS[l] + max(y0, 0) * W + max(x0, 0)) * MD) | (iy1 ? 8 : 0) | (iy0 ? 4 : 0) | (ix1 ? 2 : 0) | (ix0 ? 1 : 0);
+      } else {
+        rec.hy = rec.ly = rec.hx = rec.lx = rec.aW = rec.aH = 0.f;
+        rec.pk = 0;
+      }
+      recs[r * NS + s] = rec;
+    }
+  }
+  __syncthreads();
+  if (!live) return;  // whole row groups leave together (G divides 64): the DPP exchanges below stay within live groups
+  const int m = (int)(row % M);
+  const long long b = row / ((long long)Lq * M);
+  const float* vbase = value + b * (long long)S * MD + m * D + 4 * j;
+  const float4 go = ld4(gout + row * D + 4 * j);
+  const GatherRec* rr = recs + r * NS;
+  constexpr int NB = 4;
+  for (int s0 = 0; s0 < NS; s0 += NB) {
+    float red[NB][3];
 #pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+    for (int i = 0; i < NB; ++i) {
+      const bool have = s0 + i < NS;
+      const GatherRec rec = rr[have ? s0 + i : s0];
+      const int bits = rec.pk & 15;
+      const float* p00 = vbase + (rec.pk & ~15);
+      const int dx = (bits & 3) == 3 ? MD : 0, dy = (bits & 12) == 12 ? rec.rowstride : 0;
+      const float4 v0 = ld4(p00), v1 = ld4(p00 + dx), v2 = ld4(p00 + dy), v3 = ld4(p00 + dy + dx);
+      // per-corner dot products with the output gradient first: the weights then act on 4 scalars, not on 4 x D channels
+      const float d0 = go.x * v0.x + go.y * v0.y + go.z * v0.z + go.w * v0.w;
+      const float d1 = go.x * v1.x + go.y * v1.y + go.z * v1.z + go.w * v1.w;
+      const float d2 = go.x * v2.x + go.y * v2.y + go.z * v2.z + go.w * v2.w;
+      const float d3 = go.x * v3.x + go.y * v3.y + go.z * v3.z + go.w * v3.w;
+      const float ix0 = (bits & 1) ? 1.f : 0.f, ix1 = (bits & 2) ? 1.f : 0.f, iy0 = (bits & 4) ? 1.f : 0.f, iy1 = (bits & 8) ? 1.f : 0.f;
+      const float top = rec.hx * d0 + rec.lx * d1, bot = rec.hx * d2 + rec.lx * d3;          // rows ya / yb, x-interpolated
+      const float lef = ix1 * d1 - ix0 * d0, rig = ix1 * d3 - ix0 * d2;                      // d/dx along rows ya / yb
+      const float ga = rec.hy * top + rec.ly * bot;
+      const float gx = rec.aW * (rec.hy * lef + rec.ly * rig);
+      const float gy = rec.aH * (iy1 * bot - iy0 * top);
+      red[i][0] = have ? ga : 0.f;
+      red[i][1] = have ? gx : 0.f;
+      red[i][2] = have ? gy : 0.f;
+    }
+    if (G == 8 && s0 + NB <= NS) {
+      float tot[3];
+      const int sidx = reduce_scatter_g8_p4(red, j, tot);
+      if ((j & 1) == 0) {
+        const long long wi = row * NS + s0 + sidx;
+        gattn[wi] = tot[0];
+        *reinterpret_cast<float2*>(gloc + wi * 2) = make_float2(tot[1], tot[2]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        if (s0 + i >= NS) continue;
+        const float ga = group_sum<G>(red[i][0]), gx = group_sum<G>(red[i][1]), gy = group_sum<G>(red[i][2]);
+        if (j == 0) {
+          const long long wi = row * NS + s0 + i;
+          gattn[wi] = ga;
+          *reinterpret_cast<float2*>(gloc + wi * 2) = make_float2(gx, gy);
+        }
+      }
+    }
+  }
 }
 
+// ------------------------------------------------------------------------------------------------------
 // Fast backward (plain float-atomic scatter for grad_value).
 template <int G, bool SCATTER = true>
 __global__ __launch_bounds__(256) void msda_bwd_fast(const float* __restrict__ value, const int64_t* __restrict__ shapes,
@@ -275,44 +395,6 @@ __global__ __launch_bounds__(256) void msda_bwd_fast(const float* __restrict__ v
 }
 
 // ------------------------------------------------------------------------------------------------------
-// ---- cross-lane sums inside an 8-lane row group without touching LDS (DPP) ---------------------------------
-__device__ __forceinline__ float dpp_xor1(float v) {   // quad_perm [1,0,3,2]
-  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float dpp_xor2(float v) {   // quad_perm [2,3,0,1]
-  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float dpp_mirror8(float v) {   // row_half_mirror: lane i <-> 7-i inside each 8-lane group
-  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));
-}
-
-// Sum 4 samples x {ga, gx, gy} over the 8 lanes of a row as a reduce-scatter: after it, the lane pair
-// (j>>1) == s holds sample s's three totals (12 DPP moves instead of 36 LDS-crossbar shuffles).
-// v[s][c] in; returns this lane's sample index, totals in out[0..2].
-__device__ __forceinline__ int reduce_scatter_g8_p4(const float (&v)[4][3], int j, float (&out)[3]) {
-  const bool hi = (j & 4) != 0;          // step 1: partner 7-j (opposite bit 2); keep samples {0,1} (low half) or {2,3}
-  float a[2][3];
-#pragma unroll
-  for (int s = 0; s < 2; ++s)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float keep = hi ? v[2 + s][c] : v[s][c];
-      const float send = hi ? v[s][c] : v[2 + s][c];
-      a[s][c] = keep + dpp_mirror8(send);
-    }
-  const bool mid = (j & 2) != 0;         // step 2: partner j^2; keep sample 0 or 1 of the pair
-  float b[3];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const float keep = mid ? a[1][c] : a[0][c];
-    const float send = mid ? a[0][c] : a[1][c];
-    b[c] = keep + dpp_xor2(send);
-  }
-#pragma unroll
-  for (int c = 0; c < 3; ++c) out[c] = b[c] + dpp_xor1(b[c]);   // step 3: all-reduce over the last pair
-  return (hi ? 2 : 0) + (mid ? 1 : 0);
-}
-
 // Tiled backward for self-attention over the value's own pixels (Lq == S, the encoder): LDS-privatised grad_value.
 //
 // Float atomics execute at the memory side at ~1.3 TB/s chip-wide (MI355X_MICROARCH.md, "Global float atomics"); the
@@ -761,6 +843,19 @@ inline int check_common(const void* a, const void* b, const void* c, const void*
   return 0;
 }
 
+// OCPG_MSDA_COL=0 keeps the row / tiled kernels (A/B timing and parity of the older paths); default: column kernels
+inline bool col_enabled() {
+  const char* e = std::getenv("OCPG_MSDA_COL");      // read per call: tests toggle it in-process
+  return !(e && e[0] == '0');
+}
+
+// The column-tile FORWARD (LDS-staged value windows) is correct but, at config #2, slower than the row kernel
+// (185 vs 100 us: DESIGN.md section 4.1): opt-in with OCPG_MSDA_FWD=col.
+inline bool col_fwd_enabled() {
+  const char* e = std::getenv("OCPG_MSDA_FWD");
+  return col_enabled() && e && e[0] == 'c';
+}
+
 inline int launch_status() {
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
@@ -781,16 +876,21 @@ inline int launch_status() {
 
 extern "C" {
 
-const char* ocpg_hip_version(void) { return "ocpg_hip gfx950 r1"; }
+const char* ocpg_hip_version(void) { return "ocpg_hip gfx950 r2"; }
 
 int ocpg_msda_fwd_f32(const float* value, const int64_t* shapes, const int64_t* level_start, const float* loc, const float* attn,
-                      int N, int S, int M, int D, int L, int Lq, int P, float* out, void* stream) {
+                      int N, int S, int M, int D, int L, int Lq, int P, float* out, const int64_t* shapes_host, void* stream) {
   if (int e = check_common(value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P)) return e;
   const long long rows = (long long)N * Lq * M;
   if (rows == 0) return 0;
   if (!out) return -1013;
   hipStream_t st = (hipStream_t)stream;
   const int G = fast_group(D);
+  if (shapes_host && Lq == S && col_fwd_enabled() && (long long)S * M * D < (1LL << 31)) {
+    ocpg_col::ColGeom cg;
+    if (ocpg_col::make_col_geom(shapes_host, L, S, M, P, 8, 8, cg) && ocpg_col::fwd_col(value, loc, attn, N, S, M, D, P, cg, out, st))
+      return launch_status();
+  }
   const size_t rec_bytes = (size_t)L * P * sizeof(SampleRec);
   if (G && L <= kMaxLevels && (256 / G) * rec_bytes <= 48 * 1024 && (long long)S * M * D < (1LL << 31)) {
     const int rpb = 256 / G;
@@ -800,6 +900,8 @@ int ocpg_msda_fwd_f32(const float* value, const int64_t* shapes, const int64_t* 
     const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
 #endif
     const size_t lds = rpb * rec_bytes;
+    // (a mask-free variant with validity folded into the weights, as in msda_bwd_gather_row, measured 109 vs 100 us: the
+    //  forward is bound by the 16-B-per-lane gather path, not by its selects)
     FAST_DISPATCH(G, msda_fwd_fast, value, shapes, level_start, loc, attn, S, M, L, Lq, P, rows, out)
   } else {
     const unsigned grid = (unsigned)((rows + 3) / 4);
@@ -834,6 +936,22 @@ int ocpg_msda_bwd_f32(const float* value, const int64_t* shapes, const int64_t* 
   const size_t rec_bytes = (size_t)L * P * sizeof(SampleRec);
   if (G && L <= kMaxLevels && (256 / G) * rec_bytes <= 48 * 1024 && (long long)S * M * D < (1LL << 31)) {
     const int rpb = 256 / G;
+    if (shapes_host && Lq == S && col_enabled() && (G == 4 || G == 8)) {
+      // Self-attention backward = two independent kernels: the column-tile scatter (grad_value; reads loc / attn / grad_out)
+      // and the row gather (grad_loc, grad_attn; reads value too).
+      ocpg_col::ColGeom cg;
+      const char* tw = std::getenv("OCPG_MSDA_TILEW");      // experiment switch: scatter tile width on the finest level
+      if (ocpg_col::make_col_geom(shapes_host, L, S, M, P, 8, tw ? std::atoi(tw) : 16, cg) && ocpg_col::scatter_supported(cg, D, P)) {
+        // (running the two on separate streams was measured: 405 vs 415 us -- each kernel fills the chip on its own --
+        //  so they stay on the caller's stream: no library-owned stream, no events)
+        const unsigned ggrid = (unsigned)((((long long)N * Lq + rpb - 1) / rpb) * M);
+        const size_t glds = rpb * (size_t)L * P * sizeof(GatherRec);
+        ocpg_col::bwd_scatter_col(loc, attn, grad_out, N, S, M, D, P, cg, grad_value, st);
+        if (G == 4) msda_bwd_gather_row<4><<<ggrid, 256, glds, st>>>(value, shapes, level_start, loc, attn, grad_out, S, M, L, Lq, P, rows, grad_loc, grad_attn);
+        else msda_bwd_gather_row<8><<<ggrid, 256, glds, st>>>(value, shapes, level_start, loc, attn, grad_out, S, M, L, Lq, P, rows, grad_loc, grad_attn);
+        return launch_status();
+      }
+    }
     TileGeom geo;
     size_t tiled_lds = 0;
     if (shapes_host && Lq == S && L <= kMaxTileLevels && G >= 4 && G <= 16 && make_tile_geom(shapes_host, L, D, rpb, P, geo, tiled_lds)) {

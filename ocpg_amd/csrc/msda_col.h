@@ -1,0 +1,38 @@
+// Column-tile MSDeformAttn kernels (self-attention over the value's own pixels, Lq == S): shared declarations.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ocpg_col {
+
+constexpr int kMaxLevels = 4;
+constexpr int kMarginLo = 4;   // window extends this many pixels below the tile's footprint ...
+constexpr int kMarginHi = 5;   // ... and this many above (x0 + 1 is the far corner)
+
+// Host-derived tiling of one (frame, head) problem into "pyramid columns": the finest level is cut into
+// nty x ntx blocks of <= 8x8 pixels; a column owns, at EVERY level, the pixels whose index range scales to the same
+// block (rows [ty*H_l/nty, (ty+1)*H_l/nty)).  Queries of a column sample -- at every destination level -- around the
+// column's own footprint, so one small window per (column, level) catches them; anything outside the window takes a
+// direct global path, so results never depend on locality.
+struct ColGeom {
+  int L, nty, ntx, ntiles;
+  unsigned m_ntx, m_nty, m_ntiles, m_M, m_P;   // multiply-high reciprocals (no integer divide on the device)
+  int tmax;   // max queries of a column
+  int wmax;   // max window pixels of a (column, level)
+  int wrest;  // max window pixels of a column over levels 1..L-1
+  int H[kMaxLevels], W[kMaxLevels], S0[kMaxLevels];
+};
+
+// false: shapes not supported by the column kernels (caller falls back to the row kernels)
+// tile_h x tile_w: block of the finest level that defines a column (8x8 for the gather kernels, 8x16 for the scatter)
+bool make_col_geom(const int64_t* shapes_host, int L, int S, int M, int P, int tile_h, int tile_w, ColGeom& g);
+
+bool scatter_supported(const ColGeom& g, int D, int P);
+
+// Each returns 1 when it launched, 0 when the shape is not supported (nothing launched).
+int fwd_col(const float* value, const float* loc, const float* attn, int N, int S, int M, int D, int P, const ColGeom& g,
+            float* out, hipStream_t st);
+int bwd_scatter_col(const float* loc, const float* attn, const float* gout, int N, int S, int M, int D, int P, const ColGeom& g,
+                    float* gvalue, hipStream_t st);
+
+}  // namespace ocpg_col

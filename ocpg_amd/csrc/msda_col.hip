@@ -1,0 +1,605 @@
+// MSDeformAttn for self-attention over the value's own pixels (Lq == S, the deformable ENCODER) on MI355X (gfx950):
+// "pyramid column" kernels.  Semantics = models/ops/src/cuda/ms_deform_im2col_cuda.cuh:237-299 (forward), :87-159 +
+// :301-403 (backward); the mapping onto the machine is new.
+//
+// Why columns.  One (frame, head) problem has S queries (5 100 at config #2), each sampling L*P points; a query at level
+// lq, pixel (y, x) samples every level l around ITS OWN normalised position.  Cut the finest level into <= 8x8 blocks;
+// a column = one block plus the pixels of every coarser level that scale onto it (8x8 + 4x4 + 2x2 + 1 = 85 queries).
+// All samples a column takes at destination level l fall (for the offsets a deformable encoder learns: a few pixels)
+// into the column's footprint at l plus a margin: ONE small window per (column, level).
+//   * forward / backward-gather: the window of `value` is staged once in LDS with coalesced 16-B loads; the 4 bilinear
+//     corners of every sample are then ds_read_b128 (256 B/clk/CU) instead of 16-B-per-lane global gathers (the row
+//     kernels are bound by the texture-address path: 16 cycles per 1-KiB wave load -> ~85 us per call at N=10).
+//   * backward-scatter (grad_value): LDS float atomics are the wrong tool on gfx950 -- measured
+//     (tools/ubench/lds_atomic2.hip) ds_add_f32 193 cycles per wave-instruction (lane-serial), ds_add_f64 8.8 and 92 with
+//     8 lanes on one address, which is the COMMON case for coarse destination levels.  Instead the column's corner
+//     contributions (1 360 per level) are BINNED by window pixel with integer LDS atomics (counting sort), and every
+//     window pixel is then summed in REGISTERS by the 8 lanes that own it (gather form: one broadcast ds_read_b64 of the
+//     item + one ds_read_b128 of the staged grad_out row per contribution) and leaves the kernel as ONE global atomic
+//     per touched (pixel, channel).  Coarse queries share their column with the fine ones, so their sparse contributions
+//     merge with the dense ones before the flush (round 1 flushed 389 MB of atomics for a 52 MB tensor).
+//   * samples outside the window take a direct global path (loads / atomics): results never depend on locality.
+//   * every global load of a workgroup (windows of all levels, all (location, weight) pairs) is issued in the prologue:
+//     one memory round trip per workgroup, the per-level phases are LDS-only.  Index arithmetic uses multiply-high
+//     "magic" reciprocals (gfx950 has no integer divide: ~35 instructions each; the first version spent more
+//     instructions on divisions than on the bilinear arithmetic).
+#include "msda_col.h"
+
+#include <algorithm>
+
+#include "msda_dev.h"
+
+namespace ocpg_col {
+namespace {
+
+using ocpg_dev::ld4;
+
+constexpr int kNT = 384;     // threads per workgroup: 48 row groups of 8 lanes -> a column's 85 queries in 2 passes
+constexpr int kLM = 4;       // levels the column kernels are compiled for
+
+__host__ __device__ __forceinline__ unsigned magic_of(unsigned d) { return d <= 1 ? 0xffffffffu : (unsigned)(0xffffffffu / d); }
+// n / d for n < 2^31 with m = magic_of(d): the estimate is at most one low
+__device__ __forceinline__ unsigned udiv(unsigned n, unsigned d, unsigned m) {
+  unsigned q = __umulhi(n, m);
+  if (n - q * d >= d) ++q;
+  return q;
+}
+
+// Barrier for LDS hand-offs only: waits for this wave's LDS operations, NOT for its global stores / atomics
+// (__syncthreads() also drains vmcnt: every level's flush atomics would be waited for at the next barrier --
+// measured 80 us of the scatter kernel -- although nothing in the workgroup ever reads them back).
+#ifndef EXP_SYNC
+#define EXP_SYNC 1
+#endif
+__device__ __forceinline__ void lds_barrier() {
+#if EXP_SYNC
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+  __syncthreads();
+#endif
+}
+
+#ifdef EXP_STAMPS
+// Diagnostic build only (never shipped): per-phase cycle sums of wave 0 of every scatter workgroup.
+__device__ unsigned long long g_stamps[16];
+#define STAMP(k) do { if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_stamps[k], t_ - tprev); tprev = t_; } } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
+struct TileCtx {
+  int ry0[kLM], cx0[kLM], cw[kLM], nq[kLM];
+  unsigned m_cw[kLM], m_ww[kLM];
+  int qbase[kLM + 1];
+  int wy0[kLM], wx0[kLM], wh[kLM], ww[kLM];
+  int woff[kLM + 1];       // flat offset of each level's window in the column's window-pixel list
+  int H[kLM], W[kLM], S0[kLM];
+};
+
+// threads 0..L-1 fill their level, then (after a barrier) the prefix sums; ends with a barrier
+__device__ __forceinline__ void tile_setup(const ColGeom& geo, int tile, TileCtx& t, int tid) {
+  if (tid < geo.L) {
+    const int l = tid;
+    const int ty = (int)udiv(tile, geo.ntx, geo.m_ntx), tx = tile - ty * geo.ntx;
+    const int H = geo.H[l], W = geo.W[l];
+    const int ry0 = (int)udiv(ty * H, geo.nty, geo.m_nty), ry1 = (int)udiv((ty + 1) * H, geo.nty, geo.m_nty);
+    const int cx0 = (int)udiv(tx * W, geo.ntx, geo.m_ntx), cx1 = (int)udiv((tx + 1) * W, geo.ntx, geo.m_ntx);
+    t.H[l] = H; t.W[l] = W; t.S0[l] = geo.S0[l];
+    t.ry0[l] = ry0; t.cx0[l] = cx0; t.cw[l] = cx1 - cx0;
+    t.m_cw[l] = magic_of(cx1 - cx0);
+    t.nq[l] = (ry1 - ry0) * (cx1 - cx0);
+    const int fy1 = max(ry1, ry0 + 1), fx1 = max(cx1, cx0 + 1);     // footprint even when the column has no query here
+    const int wy0 = max(0, ry0 - kMarginLo), wx0 = max(0, cx0 - kMarginLo);
+    t.wy0[l] = wy0;
+    t.wx0[l] = wx0;
+    t.wh[l] = min(H, fy1 + kMarginHi) - wy0;
+    t.ww[l] = min(W, fx1 + kMarginHi) - wx0;
+    t.m_ww[l] = magic_of(t.ww[l]);
+  }
+  __syncthreads();
+  if (tid <= geo.L) {
+    int q = 0, w = 0;
+    for (int k = 0; k < tid; ++k) { q += t.nq[k]; w += t.wh[k] * t.ww[k]; }
+    t.qbase[tid] = q;
+    t.woff[tid] = w;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ int local_to_query(const TileCtx& t, int L, int i) {
+  int l = 0;
+  while (l + 1 < L && i >= t.qbase[l + 1]) ++l;
+  const int r = i - t.qbase[l];
+  const int dy = (int)udiv(r, t.cw[l], t.m_cw[l]);
+  return t.S0[l] + (t.ry0[l] + dy) * t.W[l] + t.cx0[l] + r - dy * t.cw[l];
+}
+
+// ---- sample records ----------------------------------------------------------------------------------------------------
+// Gather kernels: validity is FOLDED INTO THE WEIGHTS.  The two corner columns are xa = max(x0, 0), xb = min(x0+1, W-1)
+// (rows alike): always inside the map, so every corner address is loadable; a corner outside the map gets weight 0
+// (hx' = x0 >= 0 ? 1-lx : 0, lx' = x0+1 <= W-1 ? lx : 0, ...).  No masks, no selects in the inner loop.
+//   pk = (pix << 5) | (global << 4) | iy1 << 3 | iy0 << 2 | ix1 << 1 | ix0;   pix = pixel (ya, xa) in the window, or in the
+//   level map when global.  An invalid sample: pk = 0 and all weights 0 (it reads pixel 0 of the window and ignores it).
+struct GRec {
+  int pk;
+  float hy, ly, hx, lx;   // masked by validity
+};
+
+__device__ __forceinline__ GRec make_grec(float x_n, float y_n, int H, int W, int wy0, int wx0, int wh, int ww) {
+  GRec r;
+  const float h_im = y_n * (float)H - 0.5f, w_im = x_n * (float)W - 0.5f;
+  if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {          // cuh:268 / cuh:332
+    const int y0 = (int)floorf(h_im), x0 = (int)floorf(w_im);
+    const float ly = h_im - (float)y0, lx = w_im - (float)x0;
+    const bool iy0 = y0 >= 0, iy1 = y0 + 1 <= H - 1, ix0 = x0 >= 0, ix1 = x0 + 1 <= W - 1;
+    r.hy = iy0 ? 1.f - ly : 0.f;
+    r.ly = iy1 ? ly : 0.f;
+    r.hx = ix0 ? 1.f - lx : 0.f;
+    r.lx = ix1 ? lx : 0.f;
+    const int ya = max(y0, 0), yb = min(y0 + 1, H - 1), xa = max(x0, 0), xb = min(x0 + 1, W - 1);
+    const bool in = ya >= wy0 && yb < wy0 + wh && xa >= wx0 && xb < wx0 + ww;
+    const int pix = in ? (ya - wy0) * ww + (xa - wx0) : ya * W + xa;
+    r.pk = (pix << 5) | (in ? 0 : 16) | (iy1 ? 8 : 0) | (iy0 ? 4 : 0) | (ix1 ? 2 : 0) | (ix0 ? 1 : 0);
+  } else {
+    r.hy = r.ly = r.hx = r.lx = 0.f;
+    r.pk = 0;
+  }
+  return r;
+}
+
+// ----------------------------------------------------------------------------------------------------------------------
+// Forward with LDS-staged value windows.  NT threads = NT/G row groups of G lanes; a row group owns one query of the
+// column per pass and one float4 (4 channels) per lane.  (Opt-in, OCPG_MSDA_FWD=col: at config #2 it measures 185 us
+// against the row kernel's 100 us -- same instruction count, a third of the resident waves)
+template <int G>
+__global__ __launch_bounds__(kNT) void k_fwd_col(const float* __restrict__ value, const float* __restrict__ loc,
+                                                 const float* __restrict__ attn, int S, int M, int P, ColGeom geo,
+                                                 float* __restrict__ out) {
+  constexpr int D = 4 * G, ROWS = kNT / G, PASSES = (96 + ROWS - 1) / ROWS;
+  constexpr int WU0 = (320 + ROWS - 1) / ROWS;      // level 0's window goes registers -> LDS inside the prologue (<= 320 pixels)
+  constexpr int WU = (384 + ROWS - 1) / ROWS;       // window pixels of the OTHER levels stay in registers (<= 384 per column)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* win = reinterpret_cast<float*>(smem);                                          // [wmax][D]   (one level at a time)
+  float4* rec_w = reinterpret_cast<float4*>(smem + (size_t)geo.wmax * D * sizeof(float));  // [tmax * P]  4 corner weights * attention weight
+  int* rec_pk = reinterpret_cast<int*>(rec_w + (size_t)geo.tmax * P);                    // [tmax * P]
+  int* qg = reinterpret_cast<int*>(rec_pk + (size_t)geo.tmax * P);                       // [tmax]
+  __shared__ TileCtx tc;
+  const int tid = threadIdx.x;
+  const int bid = blockIdx.x;
+  const int bt = (int)udiv(bid, M, geo.m_M);
+  const int m = bid - bt * M;      // head fastest: blocks are dealt round-robin over the 8 XCDs -> one head per XCD L2
+  const int b = (int)udiv(bt, geo.ntiles, geo.m_ntiles), tile = bt - b * geo.ntiles;
+  tile_setup(geo, tile, tc, tid);
+  const int L = geo.L, NS = L * P, MD = M * D;
+  const int T = tc.qbase[L], TP = T * P;
+  const int r = tid / G, j = tid % G;
+  const float* vb = value + (long long)b * S * MD + m * D + 4 * j;
+  // ---- prologue: all global loads ---------------------------------------------------------------------------------
+  // (loads are UNCONDITIONAL on clamped indices: a load inside a branch makes hipcc wait for it right there -- the
+  //  first build had one s_waitcnt vmcnt per load, i.e. a dozen dependent memory round trips per workgroup)
+  float4 wreg0[WU0], wreg[WU];
+  const int wtot = tc.woff[L], w1st = tc.woff[1];
+  {
+    const int ww = tc.ww[0];
+    const unsigned mw = tc.m_ww[0];
+    const float* v0 = vb + ((long long)tc.S0[0] + (long long)tc.wy0[0] * tc.W[0] + tc.wx0[0]) * MD;
+#pragma unroll
+    for (int u = 0; u < WU0; ++u) {
+      const int px = min(r + u * ROWS, w1st - 1);
+      const int dy = (int)udiv(px, ww, mw);
+      wreg0[u] = ld4(v0 + ((long long)dy * tc.W[0] + px - dy * ww) * MD);
+    }
+  }
+  if (wtot > w1st) {       // uniform
+#pragma unroll
+    for (int u = 0; u < WU; ++u) {
+      const int idx = min(w1st + r + u * ROWS, wtot - 1);      // flat window pixel over levels 1..L-1; this lane's float4 of it
+      int l = 1;
+      while (l + 1 < L && idx >= tc.woff[l + 1]) ++l;
+      const int px = idx - tc.woff[l], ww = tc.ww[l];
+      const int dy = (int)udiv(px, ww, tc.m_ww[l]);
+      wreg[u] = ld4(vb + ((long long)tc.S0[l] + (long long)(tc.wy0[l] + dy) * tc.W[l] + tc.wx0[l] + px - dy * ww) * MD);
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < WU; ++u) wreg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int i = tid; i < T; i += kNT) qg[i] = local_to_query(tc, L, i);
+  __syncthreads();
+  // this thread's sample of every level: (query tid / P, point tid % P)
+  float2 sxy[kLM];
+  float sa[kLM];
+  {
+    const int ts = min(tid, TP - 1);
+    const int ql = (int)udiv(ts, P, geo.m_P), p = ts - ql * P;
+    const long long wi0 = (((long long)b * S + qg[ql]) * M + m) * NS + p;
+#pragma unroll
+    for (int l = 0; l < kLM; ++l) {
+      const long long wi = wi0 + min(l, L - 1) * P;
+      sxy[l] = *reinterpret_cast<const float2*>(loc + wi * 2);
+      sa[l] = attn[wi];
+    }
+  }
+  float4 acc[PASSES];
+  long long rowp[PASSES];
+#pragma unroll
+  for (int ps = 0; ps < PASSES; ++ps) {
+    const int ql = ps * ROWS + r;
+    rowp[ps] = ((long long)b * S + qg[min(ql, T - 1)]) * M + m;
+    acc[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int u = 0; u < WU0; ++u) {
+    const int px = r + u * ROWS;
+    if (px < w1st) *reinterpret_cast<float4*>(win + px * D + 4 * j) = wreg0[u];
+  }
+#pragma unroll
+  for (int l = 0; l < kLM; ++l) {
+    if (l < L) {
+      const int H = tc.H[l], W = tc.W[l], ww = tc.ww[l];
+      const float* vl = vb + (long long)tc.S0[l] * MD;
+      // (1) registers -> LDS: this level's window and records
+      if (l > 0) {
+        const int w0 = tc.woff[l], w1 = tc.woff[l + 1];
+#pragma unroll
+        for (int u = 0; u < WU; ++u) {
+          const int idx = w1st + r + u * ROWS;
+          if (idx >= w0 && idx < w1) *reinterpret_cast<float4*>(win + (idx - w0) * D + 4 * j) = wreg[u];
+        }
+      }
+      if (tid < TP) {
+        const GRec g = make_grec(sxy[l].x, sxy[l].y, H, W, tc.wy0[l], tc.wx0[l], tc.wh[l], ww);
+        rec_pk[tid] = g.pk;
+        const float a = sa[l];
+        rec_w[tid] = make_float4(g.hy * g.hx * a, g.hy * g.lx * a, g.ly * g.hx * a, g.ly * g.lx * a);
+      }
+      __syncthreads();
+      // (2) gather
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps) {
+        const int ql = ps * ROWS + r;
+        if (ql < T) {                                       // whole G-lane groups take the branch together
+          const int rb = ql * P;
+          {
+            float4 o = acc[ps];
+            for (int p0 = 0; p0 < P; p0 += 2) {
+              const bool two = p0 + 1 < P;
+              const int i0 = rb + p0, i1 = two ? i0 + 1 : i0;
+              const int pk[2] = {rec_pk[i0], rec_pk[i1]};
+              float4 w[2] = {rec_w[i0], rec_w[i1]};
+              if (!two) w[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+              float4 v[2][4];
+#pragma unroll
+              for (int i = 0; i < 2; ++i) {
+                const int pix = pk[i] >> 5;
+                const bool sx = (pk[i] & 3) == 3, sy = (pk[i] & 12) == 12;       // both columns / rows inside the map
+                if (!(pk[i] & 16)) {
+                  const float* p00 = win + pix * D + 4 * j;
+                  const int dx = sx ? D : 0, dy = sy ? ww * D : 0;
+                  v[i][0] = ld4(p00); v[i][1] = ld4(p00 + dx); v[i][2] = ld4(p00 + dy); v[i][3] = ld4(p00 + dy + dx);
+                } else {
+                  const float* p00 = vl + (long long)pix * MD;
+                  const long long dx = sx ? MD : 0, dy = sy ? (long long)W * MD : 0;
+                  v[i][0] = ld4(p00); v[i][1] = ld4(p00 + dx); v[i][2] = ld4(p00 + dy); v[i][3] = ld4(p00 + dy + dx);
+                }
+              }
+#pragma unroll
+              for (int i = 0; i < 2; ++i) {
+                o.x += w[i].x * v[i][0].x + w[i].y * v[i][1].x + w[i].z * v[i][2].x + w[i].w * v[i][3].x;
+                o.y += w[i].x * v[i][0].y + w[i].y * v[i][1].y + w[i].z * v[i][2].y + w[i].w * v[i][3].y;
+                o.z += w[i].x * v[i][0].z + w[i].y * v[i][1].z + w[i].z * v[i][2].z + w[i].w * v[i][3].z;
+                o.w += w[i].x * v[i][0].w + w[i].y * v[i][1].w + w[i].z * v[i][2].w + w[i].w * v[i][3].w;
+              }
+            }
+            acc[ps] = o;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int ps = 0; ps < PASSES; ++ps)
+    if (ps * ROWS + r < T) *reinterpret_cast<float4*>(out + rowp[ps] * D + 4 * j) = acc[ps];
+}
+
+// ----------------------------------------------------------------------------------------------------------------------
+// Backward-scatter: grad_value of one column, one destination level at a time (same latency plan: every (location,
+// weight) pair and the column's grad_out rows are loaded in the prologue).
+struct __attribute__((aligned(8))) Item {
+  float w;   // bilinear weight * attention weight
+  int q;     // float offset of the query's staged grad_out row (query index in the column * D)
+};
+
+template <int G, int NT>
+__global__ __launch_bounds__(NT) void k_scatter_col(const float* __restrict__ loc, const float* __restrict__ attn,
+                                                     const float* __restrict__ gout, int S, int M, int P, ColGeom geo,
+                                                     float* __restrict__ gvalue) {
+  constexpr int D = 4 * G, GROUPS = NT / G, NW = NT / 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* gs = reinterpret_cast<float*>(smem);                                           // [tmax][D], channel j + G*c at 4*j + c
+  Item* items = reinterpret_cast<Item*>(smem + (size_t)geo.tmax * D * sizeof(float));    // [tmax * P * 4]
+  int* qg = reinterpret_cast<int*>(items + (size_t)geo.tmax * P * 4);                    // [tmax]
+  __shared__ int cnt[NT], start[NT], nz[NT], wtot[NW];
+  __shared__ TileCtx tc;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bid = blockIdx.x;
+  const int bt = (int)udiv(bid, M, geo.m_M);
+  const int m = bid - bt * M;
+  const int b = (int)udiv(bt, geo.ntiles, geo.m_ntiles), tile = bt - b * geo.ntiles;
+#ifdef EXP_STAMPS
+  unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#endif
+  cnt[tid] = 0;
+  tile_setup(geo, tile, tc, tid);
+  STAMP(0);
+  const int L = geo.L, NS = L * P, MD = M * D;
+  const int T = tc.qbase[L], TP = T * P;
+  for (int i = tid; i < T; i += NT) qg[i] = local_to_query(tc, L, i);
+  __syncthreads();
+  const int j = tid % G;
+  const int ts = min(tid, TP - 1);
+  const int qloc = (int)udiv(ts, P, geo.m_P);           // this thread's sample of every level: (query tid / P, point tid % P)
+  float2 sxy[kLM];
+  float sa[kLM];
+  {                                                     // unconditional loads on clamped indices (see the gather kernel)
+    const int p = ts - qloc * P;
+    const long long wi0 = (((long long)b * S + qg[qloc]) * M + m) * NS + p;
+#pragma unroll
+    for (int l = 0; l < kLM; ++l) {
+      const long long wi = wi0 + min(l, L - 1) * P;
+      sxy[l] = *reinterpret_cast<const float2*>(loc + wi * 2);
+      sa[l] = attn[wi];
+    }
+  }
+  {       // stage grad_out of the column's queries, channel-interleaved per lane (tmax * G <= 2 * NT)
+    float4 gq[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int ql = min(tid / G + u * GROUPS, T - 1);
+      const float* g = gout + (((long long)b * S + qg[ql]) * M + m) * D + j;
+      gq[u] = make_float4(g[0], g[G], g[2 * G], g[3 * G]);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int ql = tid / G + u * GROUPS;
+      if (ql < T) *reinterpret_cast<float4*>(gs + ql * D + 4 * j) = gq[u];
+    }
+  }
+  __syncthreads();
+  STAMP(1);
+  float* gvb = gvalue + (long long)b * S * MD + m * D;
+#pragma unroll
+  for (int l = 0; l < kLM; ++l) {
+    if (l < L) {
+      const int H = tc.H[l], W = tc.W[l], wy0 = tc.wy0[l], wx0 = tc.wx0[l], wh = tc.wh[l], ww = tc.ww[l];
+      const int wpx = wh * ww;
+      float* gvl = gvb + (long long)tc.S0[l] * MD;
+      // (1) bin: one sample of this level per lane (TP <= NT); a window corner takes a slot in its pixel's list
+      int pix0 = 0, inm = 0, ovm = 0, slotk[4] = {0, 0, 0, 0};
+      float wk[4] = {0.f, 0.f, 0.f, 0.f};
+      if (tid < TP) {
+        const float h_im = sxy[l].y * (float)H - 0.5f, w_im = sxy[l].x * (float)W - 0.5f;
+        if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+          const int y0 = (int)floorf(h_im), x0 = (int)floorf(w_im);
+          const float ly = h_im - (float)y0, lx = w_im - (float)x0, hy = 1.f - ly, hx = 1.f - lx, a = sa[l];
+          const bool y0ok = y0 >= 0, y1ok = y0 + 1 <= H - 1, x0ok = x0 >= 0, x1ok = x0 + 1 <= W - 1;
+          const int mask = (y0ok && x0ok ? 1 : 0) | (y0ok && x1ok ? 2 : 0) | (y1ok && x0ok ? 4 : 0) | (y1ok && x1ok ? 8 : 0);
+          wk[0] = hy * hx * a; wk[1] = hy * lx * a; wk[2] = ly * hx * a; wk[3] = ly * lx * a;
+          const bool in = max(y0, 0) >= wy0 && min(y0 + 1, H - 1) < wy0 + wh && max(x0, 0) >= wx0 && min(x0 + 1, W - 1) < wx0 + ww;
+          if (in) {
+            inm = mask;
+            pix0 = (y0 - wy0) * ww + (x0 - wx0);          // may be "virtual" (row / column -1): only corners in the mask are used
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (mask & (1 << k)) slotk[k] = atomicAdd(&cnt[pix0 + (k & 1) + (k >> 1) * ww], 1);
+          } else {
+            ovm = mask;
+            pix0 = y0 * W + x0;
+          }
+        }
+      }
+      {
+        // corners outside the window: straight to memory, one contribution per wave step, D lanes x 4 B contiguous
+        unsigned long long bal = __ballot(ovm != 0);
+        while (bal) {
+          const int src = __ffsll((long long)bal) - 1;
+          bal &= bal - 1;
+          const int om = __builtin_amdgcn_readlane(ovm, src), gp = __builtin_amdgcn_readlane(pix0, src),
+                    qs = __builtin_amdgcn_readlane(qloc, src);
+          float wsrc[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) wsrc[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wk[k]), src));
+          if (lane < D) {
+            const float g = gs[qs * D + 4 * (lane % G) + lane / G];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (om & (1 << k)) atomicAdd(gvl + (long long)(gp + (k & 1) + (k >> 1) * W) * MD + lane, wsrc[k] * g);
+          }
+        }
+      }
+      lds_barrier();
+      STAMP(2);
+      // (2) one scan for both the list starts and the compaction of the non-empty pixels (packed: count | flag << 16)
+      int nnz;
+      {
+        const int c = tid < wpx ? cnt[tid] : 0;
+        const int v = c | (c ? 1 << 16 : 0);
+        int s = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int t = __shfl_up(s, o, 64);
+          if (lane >= o) s += t;
+        }
+        if (lane == 63) wtot[wave] = s;
+        lds_barrier();
+        int base = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          const int t = wtot[w];
+          if (w < wave) base += t;
+          all += t;
+        }
+        nnz = all >> 16;
+        const int excl = base + s - v;
+        start[tid] = excl & 0xffff;
+        if (c) nz[excl >> 16] = tid;
+      }
+      lds_barrier();
+      STAMP(3);
+      // (3) drop the items into their lists
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (inm & (1 << k)) {
+          Item it;
+          it.w = wk[k];
+          it.q = qloc * D;
+          items[start[pix0 + (k & 1) + (k >> 1) * ww] + slotk[k]] = it;
+        }
+      lds_barrier();
+      STAMP(4);
+      // (4) every touched window pixel is summed in registers by the G lanes that own it, then flushed once
+      const unsigned mw = tc.m_ww[l];
+#ifdef EXP_NO_ACC
+      nnz = 0;
+#endif
+      for (int kk = tid / G; kk < nnz; kk += GROUPS) {
+        const int pp = nz[kk];
+        const int n = cnt[pp];
+        const Item* lst = items + start[pp];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int t = 0;
+        for (; t + 4 <= n; t += 4) {
+          const Item i0 = lst[t], i1 = lst[t + 1], i2 = lst[t + 2], i3 = lst[t + 3];
+          const float4 g0 = ld4(gs + i0.q + 4 * j), g1 = ld4(gs + i1.q + 4 * j), g2 = ld4(gs + i2.q + 4 * j),
+                       g3 = ld4(gs + i3.q + 4 * j);
+          acc.x += i0.w * g0.x + i1.w * g1.x + i2.w * g2.x + i3.w * g3.x;
+          acc.y += i0.w * g0.y + i1.w * g1.y + i2.w * g2.y + i3.w * g3.y;
+          acc.z += i0.w * g0.z + i1.w * g1.z + i2.w * g2.z + i3.w * g3.z;
+          acc.w += i0.w * g0.w + i1.w * g1.w + i2.w * g2.w + i3.w * g3.w;
+        }
+        for (; t < n; ++t) {
+          const Item i0 = lst[t];
+          const float4 g0 = ld4(gs + i0.q + 4 * j);
+          acc.x += i0.w * g0.x; acc.y += i0.w * g0.y; acc.z += i0.w * g0.z; acc.w += i0.w * g0.w;
+        }
+        const int dy = (int)udiv(pp, ww, mw);
+        float* g = gvl + ((long long)(wy0 + dy) * W + wx0 + pp - dy * ww) * MD + j;     // lane j owns channels j, j+G, j+2G, j+3G:
+#ifndef EXP_NO_FLUSH
+        atomicAdd(g, acc.x);                                                              // one instruction = 4*G contiguous bytes per pixel
+        atomicAdd(g + G, acc.y);
+        atomicAdd(g + 2 * G, acc.z);
+        atomicAdd(g + 3 * G, acc.w);
+#endif
+        if (j == 0) cnt[pp] = 0;        // ready for the next level
+      }
+      STAMP(5);
+      lds_barrier();
+      STAMP(6);
+    }
+  }
+}
+
+inline size_t gather_lds(const ColGeom& g, int D, int P) {
+  return (size_t)g.wmax * D * sizeof(float) + (size_t)g.tmax * P * (sizeof(float4) + sizeof(int)) + (size_t)g.tmax * sizeof(int);
+}
+
+inline size_t scatter_lds(const ColGeom& g, int D, int P) {
+  return (size_t)g.tmax * D * sizeof(float) + (size_t)g.tmax * P * 4 * sizeof(Item) + (size_t)g.tmax * sizeof(int);
+}
+
+inline bool gather_ok(const ColGeom& g, int D, int P) {
+  const int G = D / 4;
+  if (D % 4 || (G != 4 && G != 8)) return false;
+  const int rows = kNT / G, passes = (96 + rows - 1) / rows;
+  return g.L <= kLM && g.tmax <= rows * passes && g.tmax * P <= kNT && g.wmax <= 320 && g.wrest <= 384 && P >= 1 &&
+         gather_lds(g, D, P) <= 64 * 1024;
+}
+
+// threads of the scatter kernel for this geometry (0: not supported): one sample of a level per thread
+inline int scatter_threads(const ColGeom& g, int D, int P) {
+  const int G = D / 4;
+  if (D % 4 || (G != 4 && G != 8) || g.L > kLM || P < 1 || scatter_lds(g, D, P) > 56 * 1024) return 0;
+  for (int nt : {384, 768})
+    if (g.tmax * P <= nt && g.wmax <= nt && g.tmax * G <= 2 * nt) return nt;
+  return 0;
+}
+
+}  // namespace
+
+bool make_col_geom(const int64_t* sh, int L, int S, int M, int P, int tile_h, int tile_w, ColGeom& g) {
+  if (!sh || L < 1 || L > kLM || M < 1 || P < 1) return false;
+  long long tot = 0, best = -1;
+  int base = 0;
+  for (int l = 0; l < L; ++l) {
+    const long long H = sh[2 * l], W = sh[2 * l + 1];
+    if (H <= 0 || W <= 0 || H > (1 << 14) || W > (1 << 14)) return false;
+    g.H[l] = (int)H;
+    g.W[l] = (int)W;
+    g.S0[l] = (int)tot;
+    if (H * W > best) { best = H * W; base = l; }
+    tot += H * W;
+  }
+  if (tot != S) return false;
+  g.L = L;
+  g.nty = (g.H[base] + tile_h - 1) / tile_h;
+  g.ntx = (g.W[base] + tile_w - 1) / tile_w;
+  g.ntiles = g.nty * g.ntx;
+  g.m_ntx = magic_of(g.ntx);
+  g.m_nty = magic_of(g.nty);
+  g.m_ntiles = magic_of(g.ntiles);
+  g.m_M = magic_of(M);
+  g.m_P = magic_of(P);
+  g.tmax = 0;
+  g.wmax = 0;
+  g.wrest = 0;
+  for (int l = 0; l < L; ++l) {
+    const int rmax = (g.H[l] + g.nty - 1) / g.nty, cmax = (g.W[l] + g.ntx - 1) / g.ntx;
+    g.tmax += rmax * cmax;
+    const int wh = std::min(g.H[l], std::max(rmax, 1) + kMarginLo + kMarginHi), ww = std::min(g.W[l], std::max(cmax, 1) + kMarginLo + kMarginHi);
+    g.wmax = std::max(g.wmax, wh * ww);
+    if (l > 0) g.wrest += wh * ww;
+  }
+  return true;
+}
+
+bool scatter_supported(const ColGeom& g, int D, int P) { return scatter_threads(g, D, P) != 0; }
+
+int fwd_col(const float* value, const float* loc, const float* attn, int N, int S, int M, int D, int P, const ColGeom& g, float* out,
+            hipStream_t st) {
+  if (!gather_ok(g, D, P)) return 0;
+  const size_t lds = gather_lds(g, D, P);
+  const unsigned grid = (unsigned)((long long)N * g.ntiles * M);
+  if (D == 16) k_fwd_col<4><<<grid, kNT, lds, st>>>(value, loc, attn, S, M, P, g, out);
+  else k_fwd_col<8><<<grid, kNT, lds, st>>>(value, loc, attn, S, M, P, g, out);
+  return 1;
+}
+
+int bwd_scatter_col(const float* loc, const float* attn, const float* gout, int N, int S, int M, int D, int P, const ColGeom& g,
+                    float* gvalue, hipStream_t st) {
+  const int nt = scatter_threads(g, D, P);
+  if (!nt) return 0;
+  const size_t lds = scatter_lds(g, D, P);
+  const unsigned grid = (unsigned)((long long)N * g.ntiles * M);
+  if (D == 16) {
+    if (nt == 384) k_scatter_col<4, 384><<<grid, 384, lds, st>>>(loc, attn, gout, S, M, P, g, gvalue);
+    else k_scatter_col<4, 768><<<grid, 768, lds, st>>>(loc, attn, gout, S, M, P, g, gvalue);
+  } else {
+    if (nt == 384) k_scatter_col<8, 384><<<grid, 384, lds, st>>>(loc, attn, gout, S, M, P, g, gvalue);
+    else k_scatter_col<8, 768><<<grid, 768, lds, st>>>(loc, attn, gout, S, M, P, g, gvalue);
+  }
+  return 1;
+}
+
+}  // namespace ocpg_col
+
+#ifdef EXP_STAMPS
+extern "C" int ocpg_debug_stamps(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(ocpg_col::g_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(ocpg_col::g_stamps), z, sizeof(z)) != hipSuccess) return -2;
+  }
+  return 0;
+}
+#endif

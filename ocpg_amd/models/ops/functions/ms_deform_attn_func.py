@@ -79,10 +79,18 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
         raise RuntimeError("ms_deform_attn_forward: spatial_shapes / level_start_index must be int64")
     N, S, M, D, L, Lq, P = _dims(value, sampling_loc)
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
-    fn = lib().ocpg_msda_fwd_f32 if value.dtype == torch.float32 else lib().ocpg_msda_fwd_f64
     with torch.cuda.device(value.device), _timed("fwd_enc" if Lq == S else "fwd_dec"):
-        check(fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
-                 attn_weight.data_ptr(), N, S, M, D, L, Lq, P, out.data_ptr(), stream_ptr()), "ocpg_msda_fwd")
+        if value.dtype == torch.float32:
+            # only the opt-in LDS-window forward reads it: never pay a device-to-host copy for it
+            hs = getattr(spatial_shapes, "_ocpg_host", None) if Lq == S else None
+            check(lib().ocpg_msda_fwd_f32(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                                          sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P, out.data_ptr(),
+                                          ctypes.c_void_p(hs.data_ptr()) if hs is not None else None, stream_ptr()),
+                  "ocpg_msda_fwd")
+        else:
+            check(lib().ocpg_msda_fwd_f64(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                                          sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P, out.data_ptr(),
+                                          stream_ptr()), "ocpg_msda_fwd")
     return out
 
 
@@ -96,11 +104,12 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     grad_attn = torch.empty_like(attn_weight)
     with torch.cuda.device(value.device), _timed("bwd_enc" if Lq == S else "bwd_dec"):
         if value.dtype == torch.float32:
-            hs = _host_shapes(spatial_shapes)
+            hs = _host_shapes(spatial_shapes) if Lq == S else None
             check(lib().ocpg_msda_bwd_f32(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
                                           sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
                                           N, S, M, D, L, Lq, P, grad_value.data_ptr(), grad_loc.data_ptr(),
-                                          grad_attn.data_ptr(), ctypes.c_void_p(hs.data_ptr()), stream_ptr()), "ocpg_msda_bwd")
+                                          grad_attn.data_ptr(), ctypes.c_void_p(hs.data_ptr()) if hs is not None else None,
+                                          stream_ptr()), "ocpg_msda_bwd")
         elif value.dtype == torch.float64:
             check(lib().ocpg_msda_bwd_f64(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
                                           sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),

@@ -162,3 +162,114 @@ def test_edge_inputs(dev):
     out = f(value, shapes.to(dev), ls.to(dev), loc, attn, 64)
     from oracle import msda as om
     assert torch.allclose(out.cpu(), om.msda_c_forward(value.cpu(), shapes, ls, loc.cpu(), attn.cpu()), rtol=1e-5, atol=1e-6)
+
+
+# ---- round 2: the self-attention kernels (column-tile scatter + gather-only row kernel; LDS-window forward) -------------
+def _local_inputs(dev, N, shapes_l, M=8, D=32, P=4, noise=1.5, outliers=0.02, seed=5):
+    """Encoder-like sampling pattern (reference initialisation ms_deform_attn.py:64-78: the head's direction, 1..P pixels
+    away from the query's own pixel) plus gaussian noise and a few far outliers, so that samples fall inside the kernels'
+    LDS windows, on their edges and outside them (direct global path), and outside the map."""
+    import math
+    shapes, ls = level_start(shapes_l)
+    S = int(shapes.prod(1).sum())
+    L = len(shapes_l)
+    g = torch.Generator().manual_seed(seed)
+    refs = []
+    for (h, w) in shapes_l:
+        ys, xs = torch.meshgrid(torch.linspace(0.5, h - 0.5, h) / h, torch.linspace(0.5, w - 0.5, w) / w, indexing="ij")
+        refs.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], -1))
+    ref = torch.cat(refs, 0)[None, :, None, None, None, :]
+    th = torch.arange(M) * (2 * math.pi / M)
+    grid = torch.stack([th.cos(), th.sin()], -1)
+    grid = grid / grid.abs().max(-1, keepdim=True)[0]
+    off = grid.view(1, 1, M, 1, 1, 2) * torch.arange(1, P + 1).view(1, 1, 1, 1, P, 1)
+    off = off.expand(N, S, M, L, P, 2) + noise * torch.randn(N, S, M, L, P, 2, generator=g)
+    norm = torch.tensor([[w, h] for h, w in shapes_l], dtype=torch.float32).view(1, 1, 1, L, 1, 2)
+    loc = ref + off / norm
+    far = torch.rand(N, S, M, L, P, 1, generator=g) < outliers
+    loc = torch.where(far, torch.rand(N, S, M, L, P, 2, generator=g) * 1.3 - 0.15, loc).contiguous()
+    value = torch.randn(N, S, M, D, generator=g)
+    attn = torch.softmax(torch.randn(N, S, M, L * P, generator=g), -1).view(N, S, M, L, P)
+    go = torch.randn(N, S, M * D, generator=g)
+    return value, shapes, ls, loc, attn, go
+
+
+class _env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        import os
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *exc):
+        import os
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("shapes_l", [[(48, 80), (24, 40), (12, 20), (6, 10)],      # config #2
+                                       [(60, 108), (30, 54), (15, 27), (8, 14)],     # config #5 (ragged level sizes)
+                                       [(32, 32), (16, 16), (8, 8)],                 # config #1: 3 levels
+                                       [(13, 7), (5, 9)]],                           # non-pyramid: levels that do not nest
+                         ids=["cfg2", "cfg5", "cfg1_3lvl", "ragged"])
+def test_self_attention_kernels_vs_c_oracle(dev, shapes_l):
+    """Forward + backward on locality-structured inputs, element-wise against the C oracle (one frame keeps the CPU side
+    to seconds), for every path that serves Lq == S: default (row forward, column scatter + row gather backward),
+    the LDS-window forward (OCPG_MSDA_FWD=col) and the round-1 kernels (OCPG_MSDA_COL=0)."""
+    from oracle import msda as om
+    from ocpg_amd.models.ops.functions import ms_deform_attn_backward, ms_deform_attn_forward
+    value, shapes, ls, loc, attn, go = _local_inputs(dev, 1, shapes_l)
+    oc = om.msda_c_forward(value, shapes, ls, loc, attn)
+    ogv, ogl, oga = om.msda_c_backward(value, shapes, ls, loc, attn, go)
+    dv, dl, da, dg = (t.to(dev) for t in (value, loc, attn, go))
+    ds, dls = shapes.to(dev), ls.to(dev)
+    ds._ocpg_host = shapes
+    for env in ({}, {"OCPG_MSDA_FWD": "col"}, {"OCPG_MSDA_COL": "0"}):
+        with _env(**env):
+            out = ms_deform_attn_forward(dv, ds, dls, dl, da)
+            gv, gl, ga = ms_deform_attn_backward(dv, ds, dls, dl, da, dg)
+        assert torch.allclose(out.cpu(), oc, rtol=1e-4, atol=1e-5), env
+        assert torch.allclose(gv.cpu(), ogv, rtol=1e-3, atol=1e-4), env
+        # grad_loc is a difference of corner values scaled by the level size (|g| up to ~1e3 here): fp32 summation order
+        # shows at ~2e-6 of the largest element (the round-1 kernels and the C oracle differ by the same amount)
+        assert (gl.cpu() - ogl).abs().max() <= 2e-5 * ogl.abs().max(), env
+        assert torch.allclose(ga.cpu(), oga, rtol=1e-3, atol=1e-4), env
+
+
+def test_self_attention_backward_paths_agree_at_bench_size(dev):
+    """N = 10 frames (what bench.py runs: 2 clips x 5 frames): column scatter + row gather against the round-1 tiled
+    kernel (itself pinned to the oracle above), plus the adjointness <out, go> == <value, grad_value>."""
+    from ocpg_amd.models.ops.functions import ms_deform_attn_backward, ms_deform_attn_forward
+    value, shapes, ls, loc, attn, go = (t.to(dev) if i != 1 else t for i, t in
+                                        enumerate(_local_inputs(dev, 10, [(48, 80), (24, 40), (12, 20), (6, 10)], seed=9)))
+    ds, dls = shapes.to(dev), ls.to(dev)
+    ds._ocpg_host = shapes
+    out = ms_deform_attn_forward(value, ds, dls, loc, attn)
+    gv, gl, ga = ms_deform_attn_backward(value, ds, dls, loc, attn, go)
+    with _env(OCPG_MSDA_COL="0"):
+        gv0, gl0, ga0 = ms_deform_attn_backward(value, ds, dls, loc, attn, go)
+    scale = gv0.abs().max()
+    assert (gv - gv0).abs().max() <= 2e-5 * scale
+    assert (gl - gl0).abs().max() <= 2e-5 * gl0.abs().max() and torch.allclose(ga, ga0, rtol=1e-3, atol=1e-4)
+    lhs = (out.double() * go.double()).sum()
+    assert torch.allclose(lhs, (gv.double() * value.double()).sum(), rtol=1e-4)
+
+
+def test_self_attention_without_host_shapes(dev):
+    """A foreign caller that has no host copy of the shapes still gets the same results (row kernels)."""
+    from ocpg_amd.models.ops.functions import ms_deform_attn_backward, ms_deform_attn_forward
+    value, shapes, ls, loc, attn, go = _local_inputs(dev, 1, [(16, 24), (8, 12)])
+    dv, dl, da, dg = (t.to(dev) for t in (value, loc, attn, go))
+    a, b_ = shapes.to(dev), shapes.to(dev)
+    a._ocpg_host = shapes
+    out1, out2 = ms_deform_attn_forward(dv, a, ls.to(dev), dl, da), ms_deform_attn_forward(dv, b_, ls.to(dev), dl, da)
+    assert torch.allclose(out1, out2, rtol=1e-5, atol=1e-6)
+    g1 = ms_deform_attn_backward(dv, a, ls.to(dev), dl, da, dg)
+    g2 = ms_deform_attn_backward(dv, b_, ls.to(dev), dl, da, dg)
+    for x, y in zip(g1, g2):
+        assert torch.allclose(x, y, rtol=1e-4, atol=1e-5)

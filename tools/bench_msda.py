@@ -1,33 +1,56 @@
-"""Micro-benchmark of the MSDeformAttn kernels at BASELINE config #2 encoder/decoder shapes (HIP events)."""
-import sys, os
+"""Micro-benchmark + A/B parity of the MSDeformAttn kernels at BASELINE config #2 encoder/decoder shapes (HIP events).
+
+OCPG_MSDA_COL=0/1 is toggled in-process: the column-tile kernels (default) against the row / tiled kernels of round 1.
+Offsets: "ring" = the reference's initialisation (ms_deform_attn.py:64-78: 1..P pixels along the head's direction),
+"ring+n" = the same plus gaussian noise (sigma 1.5 px) and 2 % far outliers, "uniform" = anywhere in the map.
+"""
+import math
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ocpg_amd.models.ops.functions import ms_deform_attn_forward, ms_deform_attn_backward
 
 dev = torch.device("cuda:0")
 shapes_l = [(48, 80), (24, 40), (12, 20), (6, 10)]
+if os.environ.get("MSDA_SHAPES") == "davis":
+    shapes_l = [(60, 108), (30, 54), (15, 27), (8, 14)]
 shapes = torch.tensor(shapes_l, dtype=torch.long)
 ls = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
 S = int(shapes.prod(1).sum())
-N, M, D, L, P = int(os.environ.get("MSDA_FRAMES", "5")), 8, 32, 4, 4
+N, M, D, L, P = int(os.environ.get("MSDA_FRAMES", "10")), 8, 32, 4, 4
+
+
+def ring_loc(noise=0.0, outliers=0.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    refs = []
+    for (h, w) in shapes_l:
+        ys, xs = torch.meshgrid(torch.linspace(0.5, h - 0.5, h) / h, torch.linspace(0.5, w - 0.5, w) / w, indexing="ij")
+        refs.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], -1))
+    ref = torch.cat(refs, 0)[None, :, None, None, None, :]
+    th = torch.arange(M) * (2 * math.pi / M)
+    grid = torch.stack([th.cos(), th.sin()], -1)
+    grid = grid / grid.abs().max(-1, keepdim=True)[0]
+    off = grid.view(1, 1, M, 1, 1, 2) * torch.arange(1, P + 1).view(1, 1, 1, 1, P, 1)
+    off = off.expand(N, S, M, L, P, 2)
+    if noise:
+        off = off + noise * torch.randn(N, S, M, L, P, 2, generator=g)
+    norm = torch.tensor([[w, h] for h, w in shapes_l], dtype=torch.float32).view(1, 1, 1, L, 1, 2)
+    loc = (ref + off / norm).contiguous()
+    if outliers:
+        far = torch.rand(N, S, M, L, P, 1, generator=g) < outliers
+        loc = torch.where(far, torch.rand(N, S, M, L, P, 2, generator=g) * 1.2 - 0.1, loc)
+    return loc
 
 
 def inputs(Lq, mode):
     g = torch.Generator().manual_seed(0)
     value = torch.randn(N, S, M, D, generator=g)
-    if mode == "ring" and Lq == S:   # the reference's init: reference point = own pixel, ring offsets of 1..4 px
-        refs = []
-        for (h, w) in shapes_l:
-            ys, xs = torch.meshgrid(torch.linspace(0.5, h - 0.5, h) / h, torch.linspace(0.5, w - 0.5, w) / w, indexing="ij")
-            refs.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], -1))
-        ref = torch.cat(refs, 0)[None, :, None, None, None, :]
-        import math
-        th = torch.arange(M) * (2 * math.pi / M)
-        grid = torch.stack([th.cos(), th.sin()], -1)
-        grid = grid / grid.abs().max(-1, keepdim=True)[0]
-        off = grid.view(1, 1, M, 1, 1, 2) * torch.arange(1, P + 1).view(1, 1, 1, 1, P, 1)
-        norm = torch.tensor([[w, h] for h, w in shapes_l], dtype=torch.float32).view(1, 1, 1, L, 1, 2)
-        loc = (ref + off / norm).expand(N, S, M, L, P, 2).contiguous()
+    if mode == "ring":
+        loc = ring_loc()
+    elif mode == "ring+n":
+        loc = ring_loc(1.5, 0.02)
     else:
         loc = torch.rand(N, Lq, M, L, P, 2, generator=g)
     attn = torch.softmax(torch.randn(N, Lq, M, L * P, generator=g), -1).view(N, Lq, M, L, P)
@@ -47,13 +70,34 @@ def timeit(fn, iters=20):
     return e0.elapsed_time(e1) / iters * 1e3  # us
 
 
-for Lq, mode in ((S, "ring"), (S, "uniform"), (5, "uniform")):
+def relerr(a, b):
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+MODES = ((S, "ring"), (S, "ring+n"), (S, "uniform"), (5, "uniform"))
+if os.environ.get("MSDA_MODES"):
+    MODES = tuple(mm for mm in MODES if mm[1] in os.environ["MSDA_MODES"].split(",") and mm[0] == S)
+COLS = tuple(os.environ.get("MSDA_COLS", "1,0").split(","))
+for Lq, mode in MODES:
     value, sh, lsi, loc, attn = inputs(Lq, mode)
     sh._ocpg_host = shapes
     go = torch.randn(N, Lq, M * D, device=dev)
     fwd_bytes = 4 * N * (S * M * D + Lq * M * D + 3 * Lq * M * L * P)
-    bwd_bytes = fwd_bytes + 4 * N * (Lq * M * D) + 4 * N * (S * M * D + 3 * Lq * M * L * P)
-    t_f = timeit(lambda: ms_deform_attn_forward(value, sh, lsi, loc, attn))
-    t_b = timeit(lambda: ms_deform_attn_backward(value, sh, lsi, loc, attn, go))
-    print(f"Lq={Lq:5d} {mode:8s} fwd {t_f:8.1f} us ({fwd_bytes / t_f / 1e6:6.2f} TB/s algo)   "
-          f"bwd(+zero fill) {t_b:8.1f} us ({bwd_bytes / t_b / 1e6:6.2f} TB/s algo)", flush=True)
+    bwd_bytes = 4 * N * (S * M * D + 3 * Lq * M * L * P + Lq * M * D) + 4 * N * (S * M * D + 3 * Lq * M * L * P)
+    res = {}
+    for col in COLS:
+        os.environ["OCPG_MSDA_COL"] = col
+        out = ms_deform_attn_forward(value, sh, lsi, loc, attn)
+        gv, gl, ga = ms_deform_attn_backward(value, sh, lsi, loc, attn, go)
+        torch.cuda.synchronize()
+        t_f = timeit(lambda: ms_deform_attn_forward(value, sh, lsi, loc, attn))
+        t_b = timeit(lambda: ms_deform_attn_backward(value, sh, lsi, loc, attn, go))
+        res[col] = (out, gv, gl, ga)
+        print(f"Lq={Lq:5d} {mode:8s} col={col} fwd {t_f:8.1f} us ({fwd_bytes / t_f / 1e6:6.2f} TB/s algo)   "
+              f"bwd(+zero fill) {t_b:8.1f} us ({bwd_bytes / t_b / 1e6:6.2f} TB/s algo)", flush=True)
+    if len(res) < 2:
+        continue
+    a, b = res["1"], res["0"]
+    print("      col vs row, max|d|/max|ref|:  out %.2e  grad_value %.2e  grad_loc %.2e  grad_attn %.2e"
+          % tuple(relerr(x, y) for x, y in zip(a, b)), flush=True)
+os.environ.pop("OCPG_MSDA_COL", None)
