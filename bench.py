@@ -9,9 +9,11 @@ dynamic mask head as in the reference's --amp path).  Data-parallel over N GPUs 
 RCCL), per-GPU work fixed => weak scaling.  Prints ONE JSON line on rank 0.
 
 Extra objects on that line:
-  roofline     -- the hand-written kernel that dominates our HIP time (MSDeformAttn backward at the encoder shape),
-                  timed live with events on the launch stream during the timed steps; achieved = algorithmic bytes
-                  per launch / mean launch time, peak = 8 TB/s HBM.
+  roofline     -- the hand-written kernel that dominates our HIP time (the grad_value scatter of the MSDeformAttn backward
+                  at the encoder shape), timed live with events on the launch stream during the timed steps; achieved =
+                  algorithmic bytes per launch / mean launch time, peak = 8 TB/s HBM.
+  kernels      -- the same for the other hand-written kernels of the step (per-launch algorithmic bytes or FLOPs, mean
+                  microseconds from live events, fraction of the HBM / vector-FP32 peak), sorted by time per step.
   cpu_baseline -- the CPU oracle (oracle/ocpg_ref.py, a restatement of the reference's path; kind "port") timed on
                   this host for a bounded sample (one clip fwd+loss+bwd), rank 0, N=1 only.
 """
@@ -28,14 +30,13 @@ import torch.utils._pytree
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 T_FRAMES, HEIGHT, WIDTH = 5, 384, 640        # BASELINE config #2/#3/#4 clip; --frames/--height/--width override (config #5: 8x480x854)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
 def model_args(device, backbone="resnet101", amp=True, roberta=False):
-    from cases import default_args
+    from ocpg_amd.opts import default_args
     return default_args(device=str(device), backbone=backbone, num_frames=T_FRAMES, num_queries=5, num_feature_levels=4,
                         enc_layers=4, dec_layers=4, hidden_dim=256, dim_feedforward=2048, dropout=0.1, amp=amp,
                         text_encoder_lazy=not roberta)
@@ -45,7 +46,7 @@ def synthetic_batch(n_clips, device, seed, roberta=False):
     """SURVEY.md section 8d recipe: randn clips (already 'normalised'), random text features (or, for config #5, captions
     that go through the random-init RoBERTa-base), one box per frame.  Widths that are not a multiple of 32 are padded
     like collate_fn does (util/misc.py:302), with the padding mask set."""
-    from synth import synthetic_targets
+    from ocpg_amd.util.synthetic import synthetic_targets
     from ocpg_amd.models.text_encoder.text_encoder import PrecomputedText
     from ocpg_amd.util.misc import NestedTensor, tag_rect_mask
     g = torch.Generator(device="cpu").manual_seed(seed)
@@ -250,6 +251,84 @@ def time_msda_kernels(n_frames, device, iters=20):
     return out
 
 
+VALU_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32 vector peak
+
+
+def _esz(code):
+    return 4 if code == 0 else 2
+
+
+# symbol -> (bound, work of one call from its arguments as passed): algorithmic bytes (each operand once) or FLOPs
+LIB_WORK = {
+    "ocpg_bn_act_fwd": ("hbm", lambda a: a[5] * a[6] * a[7] * _esz(a[9]) * (2 + bool(a[3]))),
+    "ocpg_bn_act_bwd": ("hbm", lambda a: a[5] * a[6] * a[7] * _esz(a[9]) * (2 + bool(a[3]) + bool(a[4] and a[4] != a[0]))),
+    "ocpg_dropout_add_ln_fwd": ("hbm", lambda a: a[4] * a[5] * (_esz(a[10]) + 4 + 4)),
+    "ocpg_dropout_add_ln_bwd": ("hbm", lambda a: a[6] * a[7] * (4 + _esz(a[11]) + 4 + (_esz(a[11]) if a[12] else 0) + (4 if a[13] else 0))),
+    "ocpg_bias_relu_dropout_fwd": ("hbm", lambda a: a[2] * a[3] * _esz(a[7]) * 2),
+    "ocpg_bias_relu_dropout_bwd": ("hbm", lambda a: a[2] * a[3] * _esz(a[5]) * 3),
+    "ocpg_dynmask_fwd_f32": ("valu", lambda a: a[3] * a[4] * a[6] * a[7] * (2 * 16 * (a[5] + 2) + 2 * 16 * 16)),
+    "ocpg_dynmask_bwd_f32": ("valu", lambda a: 2 * a[3] * a[4] * a[6] * a[7] * (2 * 16 * (a[5] + 2) + 2 * 16 * 16)),
+}
+
+
+def lib_work(name, args):
+    f = LIB_WORK.get(name)
+    try:
+        return float(f[1](args)) if f else None
+    except (TypeError, IndexError):
+        return None
+
+
+def kernel_table(msda_kt, lib_kt, n_frames, steps, lib_steps):
+    """Per-kernel roofline rows from the live event timings.  Algorithmic bytes / FLOPs per launch follow DESIGN.md section 4
+    (what the kernel must read and write once; fp32 unless the call says bf16)."""
+    hp, wp = (HEIGHT + 31) // 32 * 32, (WIDTH + 31) // 32 * 32
+    S, M, D, LP = sum((hp // 8 >> i) * (wp // 8 >> i) for i in range(4)), 8, 32, 16
+    v, la, o = 4 * n_frames * S * M * D, 4 * n_frames * 3 * S * M * LP, 4 * n_frames * S * M * D     # value, loc+attn, out bytes
+    msda_bytes = {"fwd_enc": v + la + o,                    # read value, loc, attn; write out
+                  "bwd_enc_value": la + o + v,              # read loc, attn, grad_out; write grad_value
+                  "bwd_enc_locattn": v + la + o + la,       # read value, loc, attn, grad_out; write grad_loc, grad_attn
+                  "bwd_enc": v + la + o + v + la}           # the whole backward when one call serves it
+    rows = []
+    for k, d in msda_kt.items():
+        if d["n"]:
+            us = d["ms"] / d["n"] * 1e3
+            row = {"kernel": "msda_" + k, "us": us, "launches_per_step": d["n"] / steps}
+            if k in msda_bytes:
+                row.update(bound="hbm", algorithmic_bytes=msda_bytes[k], achieved_GBs=msda_bytes[k] / us / 1e3,
+                           frac=msda_bytes[k] / us / 1e3 / HBM_PEAK_GBS)
+            rows.append(row)
+
+    for k, d in lib_kt.items():
+        if not d["n"]:
+            continue
+        us = d["ms"] / d["n"] * 1e3
+        row = {"kernel": k, "us": us, "launches_per_step": d["n"] / lib_steps}
+        if d["modelled"] == d["n"] and d["work"] > 0:
+            q = d["work"] / d["n"]
+            if LIB_WORK[k][0] == "hbm":
+                row.update(bound="hbm", algorithmic_bytes=q, achieved_GBs=q / us / 1e3, frac=q / us / 1e3 / HBM_PEAK_GBS)
+            else:
+                row.update(bound="valu_fp32", flops=q, achieved_TFLOPs=q / us / 1e6, frac=q / us / 1e6 / VALU_PEAK_TFLOPS)
+        rows.append(row)
+    rows.sort(key=lambda r: -r["us"] * r["launches_per_step"])
+    return rows
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks through torch.distributed.run as a CHILD process (this
+    process has not touched the GPU and never will) and exit with its code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def cpu_baseline(state_shapes):
     """Time the CPU oracle (a restatement of the reference path) on ONE clip: forward + criterion + backward."""
     try:
@@ -283,6 +362,8 @@ def main():
     a = ap.parse_args()
     T_FRAMES, HEIGHT, WIDTH = a.frames, a.height, a.width
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -367,7 +448,7 @@ def main():
         step()
     sync()
     if not a.no_kernel_timing and mode == "eager":
-        msda_fn.enable_kernel_timing(True)
+        msda_fn.enable_kernel_timing(True)          # 24 event pairs per step: no measurable host cost
     t0 = time.perf_counter()
     losses = []
     for _ in range(a.steps):
@@ -389,6 +470,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = t.item()
     kt = msda_fn.collect_kernel_timing() if (not a.no_kernel_timing and mode == "eager") else {}
+    lib_kt, lib_steps = {}, 3
+    if not a.no_kernel_timing and mode == "eager" and rank == 0 and world == 1:
+        # every other library call, timed over a few EXTRA steps outside the timed region (an event pair around each of
+        # ~500 calls per step costs host time in a launch-bound step: measured +20 ms per step)
+        _lib.enable_kernel_timing(True)
+        for _ in range(lib_steps):
+            step()
+        lib_kt = _lib.collect_kernel_timing(lib_work)
     if not a.no_kernel_timing and mode != "eager" and rank == 0:
         kt = time_msda_kernels(a.clips_per_gpu * T_FRAMES, device)
 
@@ -405,27 +494,25 @@ def main():
                            else "10-word captions through a random-init RoBERTa-base (frozen)", "launch": mode},
         "final_loss": float(loss.detach()),
     }
+    line["ranks"] = {"world_size": dist.get_world_size() if world > 1 else 1, "backend": dist.get_backend() if world > 1 else None}
     if rank == 0:
-        key = "bwd_enc"
-        if key in kt and kt[key]["n"]:
-            n_frames = a.clips_per_gpu * T_FRAMES
-            hp, wp = (HEIGHT + 31) // 32 * 32, (WIDTH + 31) // 32 * 32
-            S, M, D, LP = sum((hp // 8 >> i) * (wp // 8 >> i) for i in range(4)), 8, 32, 16
-            fwd_b = 4 * n_frames * (S * M * D + S * M * D + 3 * S * M * LP)
-            bwd_b = fwd_b + 4 * n_frames * (S * M * D) + 4 * n_frames * (S * M * D + 3 * S * M * LP)
-            us = kt[key]["ms"] / kt[key]["n"] * 1e3
-            ach = bwd_b / us / 1e3
+        rows = kernel_table(kt, lib_kt, a.clips_per_gpu * T_FRAMES, a.steps, lib_steps)
+        dom = next((r for r in rows if r["kernel"] in ("msda_bwd_enc_value", "msda_bwd_enc") and "frac" in r), None)
+        if dom is not None:
             traffic = None          # HBM bytes per launch from the committed rocprofv3 --pmc passes (same shape, same kernel)
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_msda_pmc.json")))
-                if pmc["n_frames"] == n_frames and (HEIGHT, WIDTH) == (384, 640):
-                    traffic = pmc["msda_bwd_tiled"]["hbm_bytes_per_launch"]
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_msda_pmc.json")))
+                if pmc["n_frames"] == a.clips_per_gpu * T_FRAMES and (HEIGHT, WIDTH) == (384, 640):
+                    traffic = pmc["k_scatter_col"]["hbm_bytes_per_launch"]
             except (OSError, KeyError, ValueError):
                 pass
-            line["roofline"] = {"bound": "hbm", "kernel": "msda_bwd (encoder shape, N=%d frames)" % n_frames, "achieved": ach,
-                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                                "launch_us": us, "algorithmic_bytes": bwd_b, "launches_timed": kt[key]["n"]}
-            line["kernel_us"] = {k: v["ms"] / max(v["n"], 1) * 1e3 for k, v in kt.items()}
+            line["roofline"] = {"bound": "hbm", "kernel": "k_scatter_col (grad_value of the MSDeformAttn backward, encoder shape, N=%d frames)"
+                                                          % (a.clips_per_gpu * T_FRAMES),
+                                "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": traffic,
+                                "launch_us": dom["us"], "algorithmic_bytes": dom["algorithmic_bytes"],
+                                "launches_timed": int(round(dom["launches_per_step"] * a.steps))}
+        if rows:
+            line["kernels"] = rows[:12]
         if world == 1 and not a.no_cpu_baseline and a.backbone.startswith("resnet"):
             line["cpu_baseline"] = cpu_baseline({k: tuple(v.shape) for k, v in model.state_dict().items() if v.dtype.is_floating_point})
         print(json.dumps(line), flush=True)

@@ -59,6 +59,18 @@ int ocpg_msda_bwd_f32(const float* value, const int64_t* shapes, const int64_t* 
                       int N, int S, int M, int D, int L, int Lq, int P,
                       float* grad_value, float* grad_loc, float* grad_attn,
                       const int64_t* shapes_host, void* stream);
+/* The two independent halves of ocpg_msda_bwd_f32 on their own (same contract; return -2000 when the shape is not
+ * served by the dedicated kernel -- call ocpg_msda_bwd_f32 then).  A caller that needs only some of the gradients
+ * (ctx.needs_input_grad of ms_deform_attn_func.py:30-39), or that wants the two kernels timed separately, binds these:
+ *   _value:   grad_value (+=) from loc / attn / grad_out alone (column-tile bin-and-sum scatter; needs shapes_host, Lq == S)
+ *   _locattn: grad_loc and grad_attn (overwritten) -- gather-only row kernel, any Lq */
+int ocpg_msda_bwd_value_f32(const float* loc, const float* attn, const float* grad_out,
+                            int N, int S, int M, int D, int L, int Lq, int P,
+                            float* grad_value, const int64_t* shapes_host, void* stream);
+int ocpg_msda_bwd_locattn_f32(const float* value, const int64_t* shapes, const int64_t* level_start,
+                              const float* loc, const float* attn, const float* grad_out,
+                              int N, int S, int M, int D, int L, int Lq, int P,
+                              float* grad_loc, float* grad_attn, void* stream);
 int ocpg_msda_bwd_f64(const double* value, const int64_t* shapes, const int64_t* level_start,
                       const double* loc, const double* attn, const double* grad_out,
                       int N, int S, int M, int D, int L, int Lq, int P,
@@ -119,7 +131,7 @@ int ocpg_col2im3x3_nhwc(const void* dcols, int N, int H, int W, int C, int strid
  * their gradients; same hipBLASLt kernels, ~1/3 of the host cost per call (the step is launch-bound).
  * Row-major:  C[M,N] = alpha * op(A) op(B) + beta * C (+ bias[N]);  op(A) = A [M,K] (lda) or A^T with A stored [K,M];
  * op(B) = B [K,N] (ldb) or B^T with B stored [N,K].  batch > 1: strided batches (element strides).  dtype / out_dtype:
- * 0 fp32, 1 bf16, 2 fp16 (fp32 accumulation).  One 64-MB workspace is shared: calls must be stream-ordered. */
+ * 0 fp32, 1 bf16, 2 fp16 (fp32 accumulation).  State (handle, plans) is per device, the 64-MB workspace per (device, stream). */
 int ocpg_gemm(const void* A, const void* B, void* C, const void* bias, int dtype, int out_dtype, int transA, int transB,
               long long M, long long N, long long K, long long lda, long long ldb, long long ldc, long long batch,
               long long strideA, long long strideB, long long strideC, float alpha, float beta, void* stream);

@@ -21,6 +21,8 @@ SIGNATURES = {
     "ocpg_msda_fwd_f32": [_vp, _i64p, _i64p, _vp, _vp] + [_int] * 7 + [_vp, _vp, _vp],
     "ocpg_msda_fwd_f64": [_vp, _i64p, _i64p, _vp, _vp] + [_int] * 7 + [_vp, _vp],
     "ocpg_msda_bwd_f32": [_vp, _i64p, _i64p, _vp, _vp, _vp] + [_int] * 7 + [_vp, _vp, _vp, _vp, _vp],
+    "ocpg_msda_bwd_value_f32": [_vp, _vp, _vp] + [_int] * 7 + [_vp, _vp, _vp],
+    "ocpg_msda_bwd_locattn_f32": [_vp, _i64p, _i64p, _vp, _vp, _vp] + [_int] * 7 + [_vp, _vp, _vp],
     "ocpg_msda_bwd_f64": [_vp, _i64p, _i64p, _vp, _vp, _vp] + [_int] * 7 + [_vp, _vp, _vp, _vp],
     "ocpg_bn_act_fwd": [_vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _int, ctypes.c_longlong, _int, _int, _vp],
     "ocpg_bn_act_bwd": [_vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _int, ctypes.c_longlong, _int, _int, _vp],
@@ -54,6 +56,60 @@ SIGNATURES = {
 }
 
 
+# ---- optional live kernel timing (bench.py): HIP events on the launch stream around every library call ----------
+_TIMING = {"on": False, "events": []}
+_UNTIMED = ("ocpg_gemm_plans", "ocpg_bias_relu_dropout_bwd_slots", "ocpg_dropout_add_ln_bwd_slots")
+
+
+def enable_kernel_timing(on=True):
+    _TIMING["on"] = on
+    _TIMING["events"] = []
+
+
+def collect_kernel_timing(work=None):
+    """-> {symbol: {"ms": total, "n": calls, "work": sum of work(symbol, args) over the calls}}; `work` maps a call's
+    arguments (pointers and scalars as passed) to its algorithmic bytes / FLOPs, or None.  (MSDeformAttn is timed by its own
+    wrapper, which knows the encoder / decoder shape: ops/functions/ms_deform_attn_func.py.)"""
+    torch.cuda.synchronize()
+    out = {}
+    for name, args, e0, e1 in _TIMING["events"]:
+        d = out.setdefault(name, {"ms": 0.0, "n": 0, "work": 0.0, "modelled": 0})
+        d["ms"] += e0.elapsed_time(e1)
+        d["n"] += 1
+        w = work(name, args) if work is not None else None
+        if w is not None:
+            d["work"] += w
+            d["modelled"] += 1
+    _TIMING["events"] = []
+    _TIMING["on"] = False
+    return out
+
+
+class _Lib:
+    """Attribute proxy over the CDLL: every kernel entry point can be bracketed by events when timing is on."""
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+
+    def __getattr__(self, name):
+        fn = getattr(self._cdll, name)
+        if name not in SIGNATURES or name in _UNTIMED or name.startswith("ocpg_msda_"):
+            setattr(self, name, fn)
+            return fn
+
+        def call(*a):
+            if not _TIMING["on"]:
+                return fn(*a)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*a)
+            e1.record()
+            _TIMING["events"].append((name, tuple(getattr(x, "value", x) for x in a), e0, e1))
+            return rc
+        setattr(self, name, call)
+        return call
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -70,7 +126,7 @@ def lib():
         L.ocpg_gemm_plans.restype = ctypes.c_longlong
         L.ocpg_bias_relu_dropout_bwd_slots.restype = ctypes.c_longlong
         L.ocpg_dropout_add_ln_bwd_slots.restype = ctypes.c_longlong
-        _lib = L
+        _lib = _Lib(L)
     return _lib
 
 

@@ -49,16 +49,56 @@ struct Plan {
 };
 
 constexpr size_t kWorkspaceBytes = 64u << 20;
+constexpr size_t kMaxPlans = 4096;        // variable-resolution training adds a plan per distinct M per layer: bounded
+constexpr int kMaxDevices = 64;
 
+// One state PER DEVICE (handle, plans) and one workspace per (device, stream): a process that drives a second GPU, or
+// issues GEMMs on two streams, never shares a workspace or hands a pointer of another device to hipBLASLt.
 struct State {
   std::mutex mu;
   hipblasLtHandle_t handle = nullptr;
-  void* workspace = nullptr;
+  std::unordered_map<hipStream_t, void*> workspaces;
   std::unordered_map<Key, Plan, KeyHash> plans;
 };
-State& state() {
-  static State s;
-  return s;
+State* state() {
+  static State table[kMaxDevices];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+  return &table[dev];
+}
+
+void destroy(Plan& p) {
+  if (p.a) hipblasLtMatrixLayoutDestroy(p.a);
+  if (p.b) hipblasLtMatrixLayoutDestroy(p.b);
+  if (p.c) hipblasLtMatrixLayoutDestroy(p.c);
+  if (p.desc) hipblasLtMatmulDescDestroy(p.desc);
+}
+
+// handle + this stream's workspace (call with s.mu held); 0 or an error code
+int prepare(State& s, hipStream_t st, void** ws) {
+  if (!s.handle && hipblasLtCreate(&s.handle) != HIPBLAS_STATUS_SUCCESS) return -1100;
+  auto it = s.workspaces.find(st);
+  if (it == s.workspaces.end()) {
+    void* w = nullptr;
+    if (hipMalloc(&w, kWorkspaceBytes) != hipSuccess) return -1099;
+    it = s.workspaces.emplace(st, w).first;
+  }
+  *ws = it->second;
+  return 0;
+}
+
+Plan build(State& s, const Key& key);
+
+Plan& plan_for(State& s, const Key& key) {
+  auto it = s.plans.find(key);
+  if (it == s.plans.end()) {
+    if (s.plans.size() >= kMaxPlans) {          // simplest bounded policy: start over (plans are rebuilt on demand)
+      for (auto& kv : s.plans) destroy(kv.second);
+      s.plans.clear();
+    }
+    it = s.plans.emplace(key, build(s, key)).first;
+  }
+  return it->second;
 }
 
 hipDataType hip_type(int dtype) { return dtype == 0 ? HIP_R_32F : dtype == 1 ? HIP_R_16BF : HIP_R_16F; }
@@ -125,20 +165,18 @@ extern "C" int ocpg_gemm(const void* A, const void* B, void* C, const void* bias
   if (!A) return -1001;
   if (!B) return -1002;
   if (!C) return -1003;
-  State& s = state();
+  State* sp = state();
+  if (!sp) return -1098;
+  State& s = *sp;
   std::lock_guard<std::mutex> lock(s.mu);
-  if (!s.handle) {
-    if (hipblasLtCreate(&s.handle) != HIPBLAS_STATUS_SUCCESS) return -1100;
-    if (hipMalloc(&s.workspace, kWorkspaceBytes) != hipSuccess) return -1099;
-  }
+  void* workspace = nullptr;
+  if (int e = prepare(s, (hipStream_t)stream, &workspace)) return e;
   const Key key{dtype, out_dtype, transA != 0, transB != 0, bias != nullptr, beta == 0.f, 0, M, N, K, lda, ldb, ldc, batch,
                 batch > 1 ? strideA : 0, batch > 1 ? strideB : 0, batch > 1 ? strideC : 0};
-  auto it = s.plans.find(key);
-  if (it == s.plans.end()) it = s.plans.emplace(key, build(s, key)).first;
-  Plan& p = it->second;
+  Plan& p = plan_for(s, key);
   if (p.status) return p.status;
   if (bias) hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias));
-  const hipblasStatus_t st = hipblasLtMatmul(s.handle, p.desc, &alpha, B, p.a, A, p.b, &beta, C, p.c, C, p.c, &p.algo, s.workspace,
+  const hipblasStatus_t st = hipblasLtMatmul(s.handle, p.desc, &alpha, B, p.a, A, p.b, &beta, C, p.c, C, p.c, &p.algo, workspace,
                                              p.workspace, (hipStream_t)stream);
   return st == HIPBLAS_STATUS_SUCCESS ? 0 : -1200 - (int)st;
 }
@@ -154,26 +192,25 @@ extern "C" int ocpg_gemm_bn_act(const void* A, const void* W, void* D, const flo
   if (!W) return -1002;
   if (!D) return -1003;
   if (!scale || !shift) return -1004;
-  State& s = state();
+  State* sp = state();
+  if (!sp) return -1098;
+  State& s = *sp;
   std::lock_guard<std::mutex> lock(s.mu);
-  if (!s.handle) {
-    if (hipblasLtCreate(&s.handle) != HIPBLAS_STATUS_SUCCESS) return -1100;
-    if (hipMalloc(&s.workspace, kWorkspaceBytes) != hipSuccess) return -1099;
-  }
+  void* workspace = nullptr;
+  if (int e = prepare(s, (hipStream_t)stream, &workspace)) return e;
   const Key key{dtype, dtype, 0, 1, 1, skip == nullptr, (relu ? 1 : 0) | 2 | 4, M, N, K, K, K, N, 1, 0, 0, 0};
-  auto it = s.plans.find(key);
-  if (it == s.plans.end()) it = s.plans.emplace(key, build(s, key)).first;
-  Plan& p = it->second;
+  Plan& p = plan_for(s, key);
   if (p.status) return p.status;
   hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &shift, sizeof(shift));
   const float beta = skip ? 1.f : 0.f;
   const hipblasStatus_t st = hipblasLtMatmul(s.handle, p.desc, scale, W, p.a, A, p.b, &beta, skip ? skip : D, p.c, D, p.c, &p.algo,
-                                             s.workspace, p.workspace, (hipStream_t)stream);
+                                             workspace, p.workspace, (hipStream_t)stream);
   return st == HIPBLAS_STATUS_SUCCESS ? 0 : -1200 - (int)st;
 }
 
-extern "C" long long ocpg_gemm_plans(void) {
-  State& s = state();
-  std::lock_guard<std::mutex> lock(s.mu);
-  return (long long)s.plans.size();
+extern "C" long long ocpg_gemm_plans(void) {      // of the current device
+  State* sp = state();
+  if (!sp) return -1;
+  std::lock_guard<std::mutex> lock(sp->mu);
+  return (long long)sp->plans.size();
 }

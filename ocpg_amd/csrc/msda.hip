@@ -861,6 +861,33 @@ inline int launch_status() {
   return e == hipSuccess ? 0 : -(int)e;
 }
 
+// ---- the two halves of the self-attention backward (also exported on their own: include/ocpg_hip.h) -----------------
+// 1 = launched, 0 = shape not served by these kernels
+inline int launch_bwd_value_col(const float* loc, const float* attn, const float* grad_out, const int64_t* shapes_host, int N, int S,
+                                int M, int D, int L, int Lq, int P, float* grad_value, hipStream_t st) {
+  const int G = fast_group(D);
+  if (!(shapes_host && Lq == S && col_enabled() && (G == 4 || G == 8) && (long long)S * M * D < (1LL << 31))) return 0;
+  ocpg_col::ColGeom cg;
+  const char* tw = std::getenv("OCPG_MSDA_TILEW");      // experiment switch: scatter tile width on the finest level
+  if (!ocpg_col::make_col_geom(shapes_host, L, S, M, P, 8, tw ? std::atoi(tw) : 16, cg)) return 0;
+  return ocpg_col::bwd_scatter_col(loc, attn, grad_out, N, S, M, D, P, cg, grad_value, st);
+}
+
+inline int launch_bwd_locattn_row(const float* value, const int64_t* shapes, const int64_t* level_start, const float* loc,
+                                  const float* attn, const float* grad_out, int N, int S, int M, int D, int L, int Lq, int P,
+                                  float* grad_loc, float* grad_attn, hipStream_t st) {
+  const int G = fast_group(D);
+  if (!((G == 4 || G == 8) && L <= kMaxLevels && (long long)S * M * D < (1LL << 31))) return 0;
+  const int rpb = 256 / G;
+  const size_t glds = rpb * (size_t)L * P * sizeof(GatherRec);
+  if (glds > 48 * 1024) return 0;
+  const long long rows = (long long)N * Lq * M;
+  const unsigned ggrid = (unsigned)((((long long)N * Lq + rpb - 1) / rpb) * M);
+  if (G == 4) msda_bwd_gather_row<4><<<ggrid, 256, glds, st>>>(value, shapes, level_start, loc, attn, grad_out, S, M, L, Lq, P, rows, grad_loc, grad_attn);
+  else msda_bwd_gather_row<8><<<ggrid, 256, glds, st>>>(value, shapes, level_start, loc, attn, grad_out, S, M, L, Lq, P, rows, grad_loc, grad_attn);
+  return 1;
+}
+
 }  // namespace
 
 #define FAST_DISPATCH(G_, KERNEL, ...)                                                          \
@@ -872,6 +899,12 @@ inline int launch_status() {
     case 16: KERNEL<16><<<grid, 256, lds, st>>>(__VA_ARGS__); break;                             \
     case 32: KERNEL<32><<<grid, 256, lds, st>>>(__VA_ARGS__); break;                             \
     default: KERNEL<64><<<grid, 256, lds, st>>>(__VA_ARGS__); break;                             \
+  }
+
+#define FAST_DISPATCH_GATHER(G_, GRID_, LDS_)                                                                                     \
+  switch (G_) {                                                                                                                 \
+    case 4: msda_bwd_fast<4, false><<<GRID_, 256, LDS_, st>>>(value, shapes, level_start, loc, attn, grad_out, S, M, L, Lq, P, rows, grad_value, grad_loc, grad_attn); break; \
+    default: msda_bwd_fast<8, false><<<GRID_, 256, LDS_, st>>>(value, shapes, level_start, loc, attn, grad_out, S, M, L, Lq, P, rows, grad_value, grad_loc, grad_attn); break; \
   }
 
 extern "C" {
@@ -936,21 +969,16 @@ int ocpg_msda_bwd_f32(const float* value, const int64_t* shapes, const int64_t* 
   const size_t rec_bytes = (size_t)L * P * sizeof(SampleRec);
   if (G && L <= kMaxLevels && (256 / G) * rec_bytes <= 48 * 1024 && (long long)S * M * D < (1LL << 31)) {
     const int rpb = 256 / G;
-    if (shapes_host && Lq == S && col_enabled() && (G == 4 || G == 8)) {
-      // Self-attention backward = two independent kernels: the column-tile scatter (grad_value; reads loc / attn / grad_out)
-      // and the row gather (grad_loc, grad_attn; reads value too).
-      ocpg_col::ColGeom cg;
-      const char* tw = std::getenv("OCPG_MSDA_TILEW");      // experiment switch: scatter tile width on the finest level
-      if (ocpg_col::make_col_geom(shapes_host, L, S, M, P, 8, tw ? std::atoi(tw) : 16, cg) && ocpg_col::scatter_supported(cg, D, P)) {
-        // (running the two on separate streams was measured: 405 vs 415 us -- each kernel fills the chip on its own --
-        //  so they stay on the caller's stream: no library-owned stream, no events)
-        const unsigned ggrid = (unsigned)((((long long)N * Lq + rpb - 1) / rpb) * M);
-        const size_t glds = rpb * (size_t)L * P * sizeof(GatherRec);
-        ocpg_col::bwd_scatter_col(loc, attn, grad_out, N, S, M, D, P, cg, grad_value, st);
-        if (G == 4) msda_bwd_gather_row<4><<<ggrid, 256, glds, st>>>(value, shapes, level_start, loc, attn, grad_out, S, M, L, Lq, P, rows, grad_loc, grad_attn);
-        else msda_bwd_gather_row<8><<<ggrid, 256, glds, st>>>(value, shapes, level_start, loc, attn, grad_out, S, M, L, Lq, P, rows, grad_loc, grad_attn);
+    // Self-attention backward = two independent kernels: the column-tile scatter (grad_value; reads loc / attn / grad_out)
+    // and the row gather (grad_loc, grad_attn; reads value too).  (Running them on two streams was measured: 405 vs
+    // 415 us -- each fills the chip on its own -- so both stay on the caller's stream.)
+    if (launch_bwd_value_col(loc, attn, grad_out, shapes_host, N, S, M, D, L, Lq, P, grad_value, st)) {
+      if (launch_bwd_locattn_row(value, shapes, level_start, loc, attn, grad_out, N, S, M, D, L, Lq, P, grad_loc, grad_attn, st))
         return launch_status();
-      }
+      // (not reachable: the scatter accepts a subset of the gather's shapes) finish with the round-1 gather-only kernel
+      const unsigned ggrid = (unsigned)((((long long)N * Lq + rpb - 1) / rpb) * M);
+      FAST_DISPATCH_GATHER(G, ggrid, rpb * rec_bytes)
+      return launch_status();
     }
     TileGeom geo;
     size_t tiled_lds = 0;
@@ -1001,6 +1029,31 @@ int ocpg_msda_bwd_f32(const float* value, const int64_t* shapes, const int64_t* 
     msda_bwd_generic<float><<<grid, 256, 0, st>>>(value, shapes, level_start, loc, attn, grad_out, S, M, D, L, Lq, P, rows,
                                                   grad_value, grad_loc, grad_attn);
   }
+  return launch_status();
+}
+
+int ocpg_msda_bwd_value_f32(const float* loc, const float* attn, const float* grad_out, int N, int S, int M, int D, int L, int Lq, int P,
+                            float* grad_value, const int64_t* shapes_host, void* stream) {
+  if (N < 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq < 0 || P <= 0) return -1006;
+  if ((long long)N * Lq == 0) return 0;
+  if (!loc) return -1001;
+  if (!attn) return -1002;
+  if (!grad_out) return -1003;
+  if (!grad_value) return -1011;
+  if (!launch_bwd_value_col(loc, attn, grad_out, shapes_host, N, S, M, D, L, Lq, P, grad_value, (hipStream_t)stream)) return -2000;
+  return launch_status();
+}
+
+int ocpg_msda_bwd_locattn_f32(const float* value, const int64_t* shapes, const int64_t* level_start, const float* loc,
+                              const float* attn, const float* grad_out, int N, int S, int M, int D, int L, int Lq, int P,
+                              float* grad_loc, float* grad_attn, void* stream) {
+  if (int e = check_common(value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P)) return e;
+  if ((long long)N * Lq * M == 0) return 0;
+  if (!grad_out) return -1013;
+  if (!grad_loc) return -1014;
+  if (!grad_attn) return -1015;
+  if (!launch_bwd_locattn_row(value, shapes, level_start, loc, attn, grad_out, N, S, M, D, L, Lq, P, grad_loc, grad_attn, (hipStream_t)stream))
+    return -2000;
   return launch_status();
 }
 

@@ -4,12 +4,17 @@
 (engine.py:53-59: a NaN loss term is replaced by `x - x` of the first finite term, i.e. a zero that keeps the graph), the weighted
 total, the non-finite guard, zero_grad, then either GradScaler scale/unscale_/clip/step/update (AMP) or backward/clip/step.
 Logging (MetricLogger, image dumps, TensorBoard) is out of scope; the loss dict is returned instead.  Differences, on purpose:
-the finiteness check is done on the device and read with ONE `.item()` per step (the reference's `reduce_dict` + `.item()`),
-and the weighted total goes through `criterion.weighted_sum` (one reduction) when the criterion offers it.
+  * everything the host needs per step -- the NaN flags of the loss terms, the weighted total and the malformed-box counter of
+    the matcher / GIoU path (the reference's asserts in util/box_ops.py:75-76) -- comes back in ONE stacked readback;
+  * with a process group, that vector is all-reduced first (the reference's `reduce_dict`, engine.py:79), so every rank sees
+    the same total and the same verdict: a non-finite loss on one rank stops ALL ranks before anyone enters backward
+    (a rank-local raise would leave the others hanging in DDP's gradient all-reduce until the RCCL timeout);
+  * the weighted total goes through `criterion.weighted_sum` (one reduction) when the criterion offers it.
 """
 import math
 
 import torch
+import torch.distributed as dist
 
 
 def _weighted_total(criterion, loss_dict):
@@ -19,38 +24,64 @@ def _weighted_total(criterion, loss_dict):
     return sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)
 
 
-def substitute_nan_terms(loss_dict):
-    """engine.py:53-59, without a host sync per term: NaN terms become (finite - finite) of the first finite term."""
+def substitute_nan_terms(loss_dict, bad_flags):
+    """engine.py:53-59: NaN terms become (finite - finite) of the first finite term.  `bad_flags` = per-key booleans already on
+    the host (no sync here)."""
     keys = list(loss_dict)
-    if not keys:
+    if not any(bad_flags):
         return loss_dict
-    stacked = torch.stack([loss_dict[k].reshape(()) for k in keys])
-    bad = torch.isnan(stacked)
-    if not bool(bad.any()):          # one sync; the reference syncs once per term
-        return loss_dict
-    good = [k for k, b in zip(keys, bad.tolist()) if not b]
+    good = [k for k, b in zip(keys, bad_flags) if not b]
     out = dict(loss_dict)
     if good:
         zero = loss_dict[good[0]] - loss_dict[good[0]]
-        for k, b in zip(keys, bad.tolist()):
+        for k, b in zip(keys, bad_flags):
             if b:
                 print("loss {} is Nan!!!!".format(k))
                 out[k] = zero
     return out
 
 
+def _box_error_flag(device):
+    from .models import matcher
+    flag = matcher._BOX_ERRORS.get(device)
+    return flag
+
+
 def train_step(model, criterion, samples, captions, targets, optimizer, max_norm=0.0, amp_dtype=None, grad_scaler=None):
-    """One optimisation step.  Returns (total loss as float, loss_dict, grad_total_norm).  Raises FloatingPointError on a
-    non-finite total (the reference prints and sys.exit(1)s)."""
-    device_type = samples.tensors.device.type
-    with torch.autocast(device_type=device_type, dtype=amp_dtype, enabled=amp_dtype is not None):
+    """One optimisation step.  Returns (total loss as float -- averaged over ranks like engine.py:79-86, loss_dict,
+    grad_total_norm).  Raises FloatingPointError on a non-finite total (the reference prints and sys.exit(1)s) and
+    AssertionError on malformed boxes (util/box_ops.py:75-76) -- on every rank together."""
+    device = samples.tensors.device
+    with torch.autocast(device_type=device.type, dtype=amp_dtype, enabled=amp_dtype is not None):
         outputs = model(samples, captions, targets)
         loss_dict, *_ = criterion(outputs, targets)
-        checked = substitute_nan_terms(loss_dict)
-        losses = _weighted_total(criterion, checked) if checked is loss_dict else _weighted_total(_NoFastPath(criterion), checked)
-    loss_value = float(losses.detach())
+        keys = list(loss_dict)
+        total = _weighted_total(criterion, loss_dict)
+        # one vector for the host: [per-term NaN flags..., weighted total, malformed-box count]
+        terms = torch.stack([loss_dict[k].detach().reshape(()).float() for k in keys]) if keys else torch.zeros(0, device=device)
+        flag = _box_error_flag(device)
+        report = torch.cat([torch.isnan(terms).float(), total.detach().reshape(1).float(),
+                            (flag.reshape(1).float() if flag is not None else torch.zeros(1, device=device))])
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if world > 1:
+            dist.all_reduce(report)               # NaN in any rank's total stays NaN; flags / counters add up
+        host = report.tolist()                    # THE sync of the step
+        bad = [x > 0 for x in host[:len(keys)]]
+        loss_value = host[len(keys)] / world
+        n_bad_boxes = int(host[len(keys) + 1])
+        if n_bad_boxes:
+            if flag is not None:
+                flag.zero_()
+            raise AssertionError(f"error boxes: {n_bad_boxes} malformed (x1 < x0 or y1 < y0, or NaN) box set(s)")
+        checked = substitute_nan_terms(loss_dict, bad)
+        losses = total if checked is loss_dict else _weighted_total(_NoFastPath(criterion), checked)
+        if checked is not loss_dict:              # terms were replaced: the total the ranks agree on is the repaired one
+            rep = losses.detach().reshape(1).float().clone()
+            if world > 1:
+                dist.all_reduce(rep)
+            loss_value = float(rep) / world
     if not math.isfinite(loss_value):
-        raise FloatingPointError("Loss is {}, stopping training: {}".format(loss_value, {k: float(v) for k, v in loss_dict.items()}))
+        raise FloatingPointError("Loss is {}, stopping training: {}".format(loss_value, {k: float(v.detach()) for k, v in loss_dict.items()}))
     optimizer.zero_grad()
     params = [p for p in model.parameters() if p.requires_grad]
     if grad_scaler is not None:

@@ -1,7 +1,9 @@
 """Autograd bindings of csrc/fused_ln.hip: LayerNorm(res + dropout(x)) and dropout(relu(x W^T + b)) as single passes.
 
 The dropout masks are never stored: forward and backward evaluate the same counter-based generator on (seed, offset);
-seed = torch.initial_seed() (so torch.manual_seed governs it), offset = a per-process call counter.
+seed = torch.initial_seed() (so torch.manual_seed governs it), offset = a per-process call counter.  The counter is
+state OUTSIDE torch's generators: util/checkpoint.py saves / restores it (get_rng_state / set_rng_state below), so a resumed
+run continues the mask sequence instead of replaying it from offset 1.
 """
 import torch
 from torch.autograd import Function
@@ -16,6 +18,14 @@ _calls = [0]
 def _rng():
     _calls[0] += 1
     return torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, _calls[0]
+
+
+def get_rng_state():
+    return {"dropout_calls": _calls[0]}
+
+
+def set_rng_state(state):
+    _calls[0] = int(state.get("dropout_calls", 0))
 
 
 def _st():

@@ -102,6 +102,23 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     grad_value = torch.zeros_like(value)
     grad_loc = torch.empty_like(sampling_loc)
     grad_attn = torch.empty_like(attn_weight)
+    if value.dtype == torch.float32 and Lq == S:
+        # self-attention: the two halves of the backward are separate kernels behind their own entry points (timed apart)
+        hs = _host_shapes(spatial_shapes)
+        L_ = lib()
+        with torch.cuda.device(value.device):
+            with _timed("bwd_enc_value"):
+                rc1 = L_.ocpg_msda_bwd_value_f32(sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(), N, S, M, D, L,
+                                                 Lq, P, grad_value.data_ptr(), ctypes.c_void_p(hs.data_ptr()), stream_ptr())
+            if rc1 == 0:
+                with _timed("bwd_enc_locattn"):
+                    rc2 = L_.ocpg_msda_bwd_locattn_f32(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                                                       sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(), N, S,
+                                                       M, D, L, Lq, P, grad_loc.data_ptr(), grad_attn.data_ptr(), stream_ptr())
+                check(rc2, "ocpg_msda_bwd_locattn")
+                return grad_value, grad_loc, grad_attn
+            if rc1 != -2000:
+                check(rc1, "ocpg_msda_bwd_value")
     with torch.cuda.device(value.device), _timed("bwd_enc" if Lq == S else "bwd_dec"):
         if value.dtype == torch.float32:
             hs = _host_shapes(spatial_shapes) if Lq == S else None

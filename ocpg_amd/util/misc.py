@@ -143,7 +143,11 @@ def inverse_sigmoid(x: Tensor, eps: float = 1e-5) -> Tensor:
     [eps, 1-eps] and evaluates the same quotient): bit-identical inside (eps, 1-eps).  At the clamped ends the reference
     evaluates log(eps / 1) resp. log(1 / eps) = -+11.5129 and this log(eps / (1 - eps)) resp. log((1 - eps) / fl(eps)) =
     -11.5129 / +11.5116 (fp32 rounding of 1 - eps): <= 1.4e-3 apart where the following sigmoid has slope 1e-5, i.e. <= 2e-8
-    on any box coordinate; both have zero gradient there."""
+    on any box coordinate.
+    Gradient at the clamped ends DIFFERS from the reference: there x < eps gives log(eps / clamp(1 - x)) whose derivative
+    through the un-clamped factor is 1 / (1 - x) ~ 1 (and 1 / x ~ 1 for x > 1 - eps), while logit's backward returns 0 outside
+    [eps, 1 - eps].  It can only reach the decoder's level-0 reference points (the refined ones are detached,
+    deformable_transformer.py:387) and only when a sigmoid output saturates below 1e-5 / above 1 - 1e-5."""
     return torch.logit(x, eps)
 
 

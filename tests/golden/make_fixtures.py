@@ -17,6 +17,10 @@ source text is stored.  Fixture <-> reference map:
   matcher_crit     HungarianMatcher.forward (matcher.py:74-171) and SetCriterion.forward (criterion.py:213-254)
   e2e_tiny         OCPG.forward + criterion + backward (ocpg.py:197-447), train mode, with / without padding,
                    plus the eval-mode tail (ocpg.py:401-433)
+  e2e_d32          the same step with head_dim 32 (the MSDeformAttn kernels of the BASELINE configurations)
+  e2e_cfg1         BASELINE config #1 shapes: one frame, 256x256, 3 feature levels, 1 query
+  train_step       one iteration of engine.train_one_epoch (engine.py:29-123) with main.py:76-99's optimizer: loss, gradient
+                   norm, post-step parameters; ckpt_ref.pth = a checkpoint written by util.misc.save_on_master (main.py:229-236)
   swin3d           Video-Swin pieces (video_swin_transformer.py) -- see gen_swin3d
 """
 import json
@@ -219,11 +223,10 @@ def gen_fusion():
 
 
 # ----------------------------------------------------------------------------------------------
-def build_tiny(seed=1, **over):
+def build_tiny(seed=1, B=2, **over):
     cfg = dict(TINY)
     cfg.update(over)
     args = ref_import.reference_args(**cfg)
-    B = 2
     model, crit, _ = ref_import.build_reference_model(args, tiny_text(B))
     full = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     model.load_state_dict(synth.synth_state_dict(synth.shapes_of(model), seed=seed), strict=False)   # integer buffers keep their own values
@@ -318,11 +321,11 @@ def run_e2e(model, crit, B, T, H, W, sizes, train=True):
     return out, targets
 
 
-def gen_e2e_tiny():
+def gen_e2e(name, over, cases_, B, T, H, W, seed=1):
+    """OCPG.forward + criterion + backward in train mode (+ the eval tail) for one configuration; `cases_` = [(tag, sizes)]."""
     arrays, meta = {}, {}
-    for tag, sizes in (("nopad", [(192, 224), (192, 224)]), ("pad", [(192, 224), (160, 200)])):
-        args, cfg, model, crit, full = build_tiny()
-        B, T, H, W = 2, 2, 192, 224
+    for tag, sizes in cases_:
+        args, cfg, model, crit, full = build_tiny(seed=seed, B=B, **over)
         out, targets = run_e2e(model, crit, B, T, H, W, sizes)
         losses, *_ = crit(out, targets)
         wd = crit.weight_dict
@@ -340,21 +343,140 @@ def gen_e2e_tiny():
         gn = {k: (float(p.grad.norm()) if p.grad is not None else None) for k, p in model.named_parameters()}
         meta[f"{tag}_grad_norms"] = gn
         meta[f"{tag}_total_grad_norm"] = float(torch.norm(torch.stack([p.grad.norm() for p in model.parameters() if p.grad is not None])))
+        named = dict(model.named_parameters())
         for k in ("query_embed.weight", "transformer.level_embed", "class_embed.1.weight", "controller.layers.2.bias",
-                  "transformer.encoder.layers.0.self_attn.sampling_offsets.bias", "input_proj.3.0.bias",
+                  "transformer.encoder.layers.0.self_attn.sampling_offsets.bias", "input_proj.3.0.bias", "input_proj.2.0.bias",
                   "backbone.0.body.layer2.0.conv1.weight", "mask_refine.out_conv.weight"):
-            arrays[f"{tag}_grad_{k}"] = dict(model.named_parameters())[k].grad
+            if k in named and named[k].grad is not None:
+                arrays[f"{tag}_grad_{k}"] = named[k].grad
         meta[f"{tag}_sizes"] = sizes
         # eval tail
-        args, cfg, model, crit, full = build_tiny()
+        args, cfg, model, crit, full = build_tiny(seed=seed, B=B, **over)
         with torch.no_grad():
             oute, _ = run_e2e(model, crit, B, T, H, W, sizes, train=False)
         for k in ("pred_logits", "pred_boxes", "pred_masks", "reference_points"):
             arrays[f"{tag}_eval_{k}"] = oute[k]
-    meta.update(cfg=cfg, seed=1, B=B, T=T, H=H, W=W, state_shapes=full, float_shapes=synth.shapes_of(model),
+    meta.update(cfg=cfg, seed=seed, B=B, T=T, H=H, W=W, state_shapes=full, float_shapes=synth.shapes_of(model),
                 weight_dict={k: float(v) for k, v in wd.items()})
-    save("e2e_tiny", meta, **arrays)
+    save(name, meta, **arrays)
 
+
+def gen_e2e_tiny():
+    gen_e2e("e2e_tiny", {}, (("nopad", [(192, 224), (192, 224)]), ("pad", [(192, 224), (160, 200)])), 2, 2, 192, 224)
+
+
+def gen_e2e_d32():
+    """Same step with head_dim 32 (hidden 64 / 2 heads): the channel count of every BASELINE configuration, i.e. the
+    MSDeformAttn kernels the benchmark runs (column-tile scatter + gather-row backward, G = 8) sit inside the parity step."""
+    gen_e2e("e2e_d32", dict(nheads=2), (("pad", [(192, 224), (160, 200)]),), 2, 2, 192, 224)
+
+
+def gen_e2e_cfg1():
+    """BASELINE config #1: ResNet-50, ONE frame, 256x256, 3 feature levels, 1 query (2 levels cannot run
+    through OCPG.forward, ocpg.py:247); hidden 256 / 8 heads as in the launch scripts, 1 encoder + 1 decoder... no:
+    the layer counts are kept small (1 + 2) to bound the fixture time, the shapes that make #1 special are all here."""
+    gen_e2e("e2e_cfg1", dict(hidden_dim=256, mask_dim=256, dim_feedforward=512, nheads=8, num_feature_levels=3, num_queries=1,
+                             num_frames=1), (("nopad", [(256, 256)]),), 1, 1, 256, 256)
+
+
+def _install_engine_stubs():
+    """engine.py imports evaluation-only packages at module level (cv2, pycocotools, datasets.*_eval): name stubs."""
+    ref_import.install()
+    ref_import._mod("cv2")
+    ref_import._mod("pycocotools.coco", COCO=object)
+    ref_import._mod("pycocotools.cocoeval", COCOeval=object)
+    ds = ref_import._mod("datasets")
+    ds.coco_eval = ref_import._mod("datasets.coco_eval", CocoEvaluator=object)
+    ds.refexp_eval = ref_import._mod("datasets.refexp_eval", RefExpEvaluator=object)
+    ds.a2d_eval = ref_import._mod("datasets.a2d_eval", calculate_precision_at_k_and_iou_metrics=None,
+                                  calculate_bbox_precision_at_k_and_iou_metrics=None)
+
+
+def gen_train_step():
+    """Rows f1 / f2: ONE iteration of the reference's own engine.train_one_epoch (engine.py:29-123) on the tiny model with
+    the optimizer of main.py:76-99 (AdamW, four name-based LR groups, weight decay 5e-4, clip 0.1), then a checkpoint
+    written by the reference's util.misc.save_on_master with the dict of main.py:229-236."""
+    import argparse
+    import tempfile
+    _install_engine_stubs()
+    import engine
+    import util.misc as utils
+    from util.misc import NestedTensor
+    args, cfg, model, crit, full = build_tiny()
+    B, T, H, W = 2, 2, 192, 224
+    sizes = [(192, 224), (160, 200)]
+    x = torch.zeros(B, T, 3, H, W)
+    mask = torch.ones(B, T, H, W, dtype=torch.bool)
+    targets = []
+    for i, (h, w) in enumerate(sizes):
+        x[i, :, :, :h, :w] = synth.rand(f"e2e_clip{i}", (T, 3, h, w))
+        mask[i, :, :h, :w] = False
+        t = synth.synthetic_targets(1, T, h, w)[0]
+        t["caption"] = "a"
+        targets.append(t)
+
+    def match(n, kws):
+        return any(k in n for k in kws)
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    groups = [      # main.py:76-96
+        {"params": [p for n, p in named if not match(n, args.lr_backbone_names) and not match(n, args.lr_text_encoder_names)
+                    and not match(n, args.lr_linear_proj_names)], "lr": args.lr},
+        {"params": [p for n, p in named if match(n, args.lr_backbone_names)], "lr": args.lr_backbone},
+        {"params": [p for n, p in named if match(n, args.lr_text_encoder_names)], "lr": args.lr_text_encoder},
+        {"params": [p for n, p in named if match(n, args.lr_linear_proj_names)], "lr": args.lr * args.lr_linear_proj_mult},
+    ]
+    opt = torch.optim.AdamW(groups, lr=args.lr, weight_decay=args.weight_decay)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, [3, 5])
+    scaler = torch.amp.GradScaler("cpu", enabled=False)
+    args.amp = False
+    args.output_dir = tempfile.mkdtemp()
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    stats, _ = engine.train_one_epoch(args, model, crit, [(NestedTensor(x, mask), targets)], opt, scaler, torch.device("cpu"), 0,
+                                      max_norm=args.clip_max_norm, lr_scheduler=sched)
+    after = dict(model.named_parameters())
+    meta = {"cfg": cfg, "seed": 1, "B": B, "T": T, "H": H, "W": W, "sizes": sizes, "float_shapes": synth.shapes_of(model),
+            "loss": float(stats["loss"]), "grad_norm": float(stats["grad_norm"]), "lr": float(stats["lr"]),
+            "clip_max_norm": float(args.clip_max_norm), "weight_decay": float(args.weight_decay),
+            "group_lrs": [g["lr"] for g in opt.param_groups], "group_sizes": [len(g["params"]) for g in opt.param_groups],
+            "group_first_names": [next((n for n, p in named if p is g["params"][0]), None) if g["params"] else None for g in opt.param_groups],
+            "param_abs_sum": {k: float(v.detach().double().abs().sum()) for k, v in after.items()},
+            "param_delta_norm": {k: float((v.detach() - before[k]).double().norm()) for k, v in after.items()}}
+    arrays = {}
+    for k in ("query_embed.weight", "transformer.level_embed", "class_embed.1.weight", "controller.layers.2.bias",
+              "transformer.encoder.layers.0.self_attn.sampling_offsets.bias", "input_proj.3.0.bias", "mask_refine.out_conv.weight",
+              "bbox_embed.0.layers.2.bias", "text_proj.fc.bias"):
+        if k in after:
+            arrays["after_" + k] = after[k].detach()
+            arrays["delta_" + k] = after[k].detach() - before[k]
+    save("train_step", meta, **arrays)
+
+    # ---- f2: a checkpoint written by the reference (main.py:226-236 -> util/misc.py:444-446), small enough to commit:
+    # the same dict, restricted to the head modules (the ResNet body alone is 94 MB); optimizer rebuilt over exactly those
+    # parameters and stepped once so that its state_dict carries real exp_avg / exp_avg_sq / step entries.
+    sched.step()
+    small = ("query_embed.", "class_embed.", "bbox_embed.", "controller.", "mask_refine.", "ls_feat_viz.", "ls_text_proj.",
+             "transformer.level_embed", "transformer.reference_points.", "sentence_proj.")
+    sub = [(n, p) for n, p in model.named_parameters() if n.startswith(small) and not n.startswith("transformer.decoder.bbox_embed")]
+    opt2 = torch.optim.AdamW([{"params": [p for n, p in sub if "reference_points" not in n], "lr": args.lr},
+                              {"params": [p for n, p in sub if "reference_points" in n], "lr": args.lr * args.lr_linear_proj_mult}],
+                             lr=args.lr, weight_decay=args.weight_decay)
+    sched2 = torch.optim.lr_scheduler.MultiStepLR(opt2, [1, 5])
+    for _, p in sub:
+        p.grad = synth.rand("ck_grad_" + _, p.shape) * 1e-3
+    opt2.step()
+    sched2.step()
+    sched2.step()                      # last_epoch = 2: one milestone (epoch 1) passed -> lr * 0.1
+    path = os.path.join(HERE, "ckpt_ref.pth")
+    ns = argparse.Namespace(**{k: v for k, v in vars(args).items() if isinstance(v, (int, float, str, bool, list, tuple, type(None)))})
+    ns.output_dir = "output"
+    utils.save_on_master({"model": {n: p.detach().clone() for n, p in sub}, "optimizer": opt2.state_dict(),
+                          "lr_scheduler": sched2.state_dict(), "epoch": 1, "args": ns, "grad_scaler": scaler.state_dict()}, path)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+    meta2 = {"keys": [n for n, _ in sub], "shapes": {n: list(p.shape) for n, p in sub}, "epoch": 1,
+             "lrs_after_resume": [g["lr"] for g in opt2.param_groups], "last_epoch": sched2.last_epoch,
+             "abs_sum": {n: float(p.detach().double().abs().sum()) for n, p in sub},
+             "exp_avg_abs_sum": [float(opt2.state[p]["exp_avg"].double().abs().sum()) for _, p in sub]}
+    save("ckpt_ref_manifest", meta2)
 
 
 # head_dim is 32 at every stage (like Swin-T/S/B), so the product's fused HIP window-attention kernel is what runs on the GPU
@@ -468,7 +590,8 @@ def gen_e2e_swin():
 
 GENS = {"msda_testpy": gen_msda_testpy, "msda_cases": gen_msda_cases, "msda_module": gen_msda_module,
         "transformer": gen_transformer, "lfm": gen_lfm, "fusion": gen_fusion, "dynmask_mso": gen_dynmask_mso,
-        "matcher_crit": gen_matcher_crit, "e2e_tiny": gen_e2e_tiny,
+        "matcher_crit": gen_matcher_crit, "e2e_tiny": gen_e2e_tiny, "e2e_d32": gen_e2e_d32, "e2e_cfg1": gen_e2e_cfg1,
+        "train_step": gen_train_step,
         "swin3d": gen_swin3d, "e2e_swin": gen_e2e_swin}
 
 if __name__ == "__main__":

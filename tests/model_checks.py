@@ -120,3 +120,92 @@ def run_eval(g, tag, device, rtol, atol):
         assert got.shape == exp.shape, (k, got.shape, exp.shape)
         a = MASK_LOGIT_ATOL if k == "pred_masks" else atol
         assert torch.allclose(got, exp, rtol=rtol, atol=a), f"{tag} eval {k}: {(got - exp).abs().max().item():.3e}"
+
+
+def reference_optimizer(model, args):
+    """main.py:76-99: AdamW, four name-based LR groups."""
+    def has(n, keys):
+        return any(k in n for k in keys)
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    groups = [
+        {"params": [p for n, p in named if not has(n, args.lr_backbone_names) and not has(n, args.lr_text_encoder_names)
+                    and not has(n, args.lr_linear_proj_names)], "lr": args.lr},
+        {"params": [p for n, p in named if has(n, args.lr_backbone_names)], "lr": args.lr_backbone},
+        {"params": [p for n, p in named if has(n, args.lr_text_encoder_names)], "lr": args.lr_text_encoder},
+        {"params": [p for n, p in named if has(n, args.lr_linear_proj_names)], "lr": args.lr * args.lr_linear_proj_mult},
+    ]
+    return torch.optim.AdamW(groups, lr=args.lr, weight_decay=args.weight_decay), named
+
+
+def check_reference_iteration(g, device):
+    """tests/golden/train_step.npz = ONE iteration of the reference's engine.train_one_epoch (make_fixtures.gen_train_step)."""
+    from ocpg_amd import engine
+    from ocpg_amd.util.misc import NestedTensor
+    meta = g.meta
+    args, model, crit = build_product(meta, device)
+    B, T, H, W = meta["B"], meta["T"], meta["H"], meta["W"]
+    x, mask, targets = cases.e2e_inputs(B, T, H, W, meta["sizes"], device)
+    model.train(), crit.train()
+    opt, named = reference_optimizer(model, args)
+    assert [g_["lr"] for g_ in opt.param_groups] == meta["group_lrs"]
+    assert [len(g_["params"]) for g_ in opt.param_groups] == meta["group_sizes"]          # same tensors in the same LR groups
+    first = [next((n for n, p in named if p is g_["params"][0]), None) if g_["params"] else None for g_ in opt.param_groups]
+    assert first == meta["group_first_names"]
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    loss, _, norm = engine.train_step(model, crit, NestedTensor(x, mask), text_for(B, device), targets, opt, max_norm=meta["clip_max_norm"])
+    assert abs(loss - meta["loss"]) <= 2e-3 * abs(meta["loss"]), (loss, meta["loss"])
+    assert abs(float(norm) - meta["grad_norm"]) <= 2e-2 * meta["grad_norm"], (float(norm), meta["grad_norm"])
+    after = dict(model.named_parameters())
+    # post-step parameters: |p|_1 of every tensor, the update norm of every tensor, and whole tensors for a few of them
+    bad = []
+    for k, v in meta["param_abs_sum"].items():
+        got = float(after[k].detach().double().abs().sum())
+        if abs(got - v) > 1e-4 * abs(v) + 1e-6:
+            bad.append((k, got, v))
+    assert not bad, bad[:5]
+    bad = []
+    for k, v in meta["param_delta_norm"].items():
+        got = float((after[k].detach() - before[k]).double().norm())
+        # AdamW's first step moves every element by ~lr * sign(g): the update norm is insensitive to |g|, so this pins
+        # the group's LR, the weight decay and which tensors were stepped; elements with |g| ~ eps may differ
+        if abs(got - v) > 2e-2 * abs(v) + 1e-7:
+            bad.append((k, got, v))
+    assert len(bad) <= max(2, len(meta["param_delta_norm"]) // 100), bad[:8]
+    for key in g.keys():
+        if key.startswith("after_"):
+            name = key[len("after_"):]
+            assert torch.allclose(after[name].detach().cpu(), g[key], rtol=1e-4, atol=2e-5), name
+
+
+def check_reference_checkpoint(g, device):
+    """tests/golden/ckpt_ref.pth was WRITTEN BY THE REFERENCE (util.misc.save_on_master with main.py:229-236's dict, head modules
+    only to keep it committable).  It must load through util.checkpoint into the product's model / optimizer / scheduler, resume
+    at the decayed LR, and a file the product writes must carry the same container format and keys."""
+    import os
+    from ocpg_amd.util import checkpoint as ck
+    meta = g.meta
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ckpt_ref.pth")
+    with open(path, "rb") as f:
+        assert f.read(2) != b"PK"                                  # legacy (non-zip) container
+    state = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(state) == {"model", "optimizer", "lr_scheduler", "epoch", "args", "grad_scaler"}
+    assert list(state["model"]) == meta["keys"] and state["epoch"] == meta["epoch"]
+    args = cases.default_args(device=str(device), **cases.TINY)
+    from ocpg_amd.models import build_model
+    model, _, _ = build_model(args)
+    model.to(device)
+    named = dict(model.named_parameters())
+    assert all(k in named and list(named[k].shape) == meta["shapes"][k] for k in meta["keys"])
+    sub = [(k, named[k]) for k in meta["keys"]]
+    opt = torch.optim.AdamW([{"params": [p for n, p in sub if "reference_points" not in n], "lr": args.lr},
+                             {"params": [p for n, p in sub if "reference_points" in n], "lr": args.lr * args.lr_linear_proj_mult}],
+                            lr=args.lr, weight_decay=args.weight_decay)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, [1, 5])
+    missing, unexpected, epoch = ck.load_checkpoint(state, model, opt, sched)
+    assert not unexpected and epoch == meta["epoch"] and set(missing).isdisjoint(meta["keys"])
+    for k in meta["keys"]:
+        assert abs(float(named[k].detach().double().abs().sum()) - meta["abs_sum"][k]) <= 1e-6 * abs(meta["abs_sum"][k]) + 1e-9, k
+    got = [float(opt.state[p]["exp_avg"].double().abs().sum()) for _, p in sub]
+    assert all(abs(a - b) <= 1e-6 * abs(b) + 1e-12 for a, b in zip(got, meta["exp_avg_abs_sum"]))
+    assert sched.last_epoch == meta["last_epoch"]
+    assert all(abs(a["lr"] - b) <= 1e-15 for a, b in zip(opt.param_groups, meta["lrs_after_resume"])), ([g_["lr"] for g_ in opt.param_groups], meta["lrs_after_resume"])

@@ -23,6 +23,20 @@ def test_train_step_matches_reference(golden, msda_double, tag):
     print(res)
 
 
+@pytest.mark.parametrize("fixture,tag", [("e2e_d32", "pad"), ("e2e_cfg1", "nopad")])
+def test_train_step_matches_reference_other_configs(golden, msda_double, fixture, tag):
+    """head_dim 32 and BASELINE config #1 (one frame, 3 levels, 1 query) through the host logic (CPU, oracle MSDeformAttn)."""
+    model_checks.run_train_step(golden(fixture), tag, torch.device("cpu"), rtol=2e-4, atol=2e-5)
+
+
+def test_reference_train_iteration_and_checkpoint(golden, msda_double):
+    """Rows f1 / f2 pinned to the REFERENCE: engine.train_step reproduces one iteration of the reference's own
+    engine.train_one_epoch (loss, pre-clip gradient norm, post-step parameters under main.py:76-99's optimizer) and
+    util.checkpoint loads a checkpoint file written by the reference's util.misc.save_on_master."""
+    model_checks.check_reference_iteration(golden("train_step"), torch.device("cpu"))
+    model_checks.check_reference_checkpoint(golden("ckpt_ref_manifest"), torch.device("cpu"))
+
+
 @pytest.mark.parametrize("tag", ["nopad", "pad"])
 def test_eval_tail_matches_reference(golden, msda_double, tag):
     model_checks.run_eval(golden("e2e_tiny"), tag, torch.device("cpu"), rtol=2e-4, atol=2e-5)
@@ -50,7 +64,7 @@ def test_checkpoint_wire_format(tmp_path):
     with open(path, "rb") as f:
         assert f.read(2) != b"PK"                      # legacy (non-zip) container, as the reference writes it
     state = torch.load(path, map_location="cpu", weights_only=False)
-    assert set(state) == {"model", "optimizer", "lr_scheduler", "epoch", "args", "grad_scaler"}
+    assert set(state) == {"model", "optimizer", "lr_scheduler", "epoch", "args", "grad_scaler", "ocpg_rng"}
     torch.manual_seed(1)
     model2, _, _ = build_model(args)
     opt2 = torch.optim.AdamW([{"params": [p for p in model2.parameters() if p.requires_grad], "lr": 5e-5}], weight_decay=5e-4)
@@ -89,10 +103,85 @@ def test_engine_train_step(golden, msda_double):
     moved = sum(int(not torch.equal(v, before[k])) for k, v in model.state_dict().items())
     assert moved > 100
     a = torch.tensor(1.5, requires_grad=True)
-    fixed = engine.substitute_nan_terms({"x": a * 2, "y": a * float("nan")})
+    fixed = engine.substitute_nan_terms({"x": a * 2, "y": a * float("nan")}, [False, True])
     assert float(fixed["y"].detach()) == 0.0 and fixed["y"].requires_grad and float(fixed["x"].detach()) == 3.0
     same = {"x": a * 2}
-    assert engine.substitute_nan_terms(same) is same
+    assert engine.substitute_nan_terms(same, [False]) is same
+
+
+def test_engine_guards(golden, msda_double):
+    """The two guards of the iteration: a NaN loss TERM is replaced by a graph-carrying zero and the step still runs
+    (engine.py:53-59); a non-finite TOTAL raises before backward (engine.py:92-95); a degenerate target box reaches the
+    reference's box assertion (util/box_ops.py:75-76) instead of silently entering the GIoU loss."""
+    import cases
+    from ocpg_amd import engine
+    from ocpg_amd.util.misc import NestedTensor
+    g = golden("e2e_tiny")
+    meta = g.meta
+    args, model, crit = model_checks.build_product(meta, torch.device("cpu"))
+    B, T, H, W = meta["B"], meta["T"], meta["H"], meta["W"]
+    x, mask, targets = cases.e2e_inputs(B, T, H, W, meta["nopad_sizes"], "cpu")
+    model.train(), crit.train()
+    opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=0.0)
+
+    class OneNaN(torch.nn.Module):
+        def __init__(self, inner, key, everything=False):
+            super().__init__()
+            self.inner, self.key, self.everything, self.weight_dict = inner, key, everything, inner.weight_dict
+
+        def forward(self, out, tg):
+            losses, *rest = self.inner(out, tg)
+            losses = {k: (v * float("nan") if (self.everything or k == self.key) else v) for k, v in losses.items()}
+            return (losses, *rest)
+    key = next(k for k in crit.weight_dict if k.startswith("loss_"))
+    text = model_checks.text_for(B, "cpu")
+    loss, checked, _ = engine.train_step(model, OneNaN(crit, key), NestedTensor(x.clone(), mask.clone()), text, targets, opt)
+    assert loss == loss and float(checked[key].detach()) == 0.0          # finite total, the NaN term contributes zero
+    with pytest.raises(FloatingPointError):
+        engine.train_step(model, OneNaN(crit, key, everything=True), NestedTensor(x.clone(), mask.clone()), text, targets, opt)
+    bad = [dict(t) for t in targets]
+    bad[0]["boxes"] = bad[0]["boxes"].clone()
+    bad[0]["boxes"][:, 2] = -0.5                                           # negative width: x1 < x0
+    with pytest.raises(AssertionError, match="error boxes|boxes"):
+        engine.train_step(model, crit, NestedTensor(x.clone(), mask.clone()), text, bad, opt)
+
+
+def test_resume_past_a_milestone_keeps_the_decayed_lr():
+    """main.py:165-180: after a resume the LR must be base * gamma ** (milestones passed), not the fresh optimizer's base LR."""
+    import cases
+    from ocpg_amd.models import build_model
+    from ocpg_amd.util import checkpoint as ck
+    import argparse
+    args = cases.default_args(device="cpu", **cases.TINY)
+    model, _, _ = build_model(args)
+
+    def make():
+        params = [p for p in model.parameters() if p.requires_grad]
+        opt = torch.optim.AdamW([{"params": params[:10], "lr": 1e-4}, {"params": params[10:], "lr": 5e-5}], weight_decay=5e-4)
+        return opt, torch.optim.lr_scheduler.MultiStepLR(opt, [2, 4])
+    opt, sched = make()
+    want = []
+    for epoch in range(6):
+        want.append([g["lr"] for g in opt.param_groups])
+        opt.step()
+        sched.step()
+        if epoch == 2:                                   # checkpoint written at the end of epoch 2: one milestone passed
+            state = {"model": model.state_dict(), "optimizer": opt.state_dict(), "lr_scheduler": sched.state_dict(), "epoch": epoch,
+                     "args": argparse.Namespace(), "grad_scaler": {"scale": 1024.0, "growth_factor": 2.0, "backoff_factor": 0.5,
+                                                                   "growth_interval": 2000, "_growth_tracker": 7}}
+    opt2, sched2 = make()
+    scaler = torch.amp.GradScaler("cpu", enabled=True)
+    _, _, epoch = ck.load_checkpoint(state, model, opt2, sched2, grad_scaler=scaler)
+    assert epoch == 2
+    got = []
+    for _ in range(epoch + 1, 6):
+        got.append([g["lr"] for g in opt2.param_groups])
+        opt2.step()
+        sched2.step()
+    for a, b in zip(got, want[epoch + 1:]):
+        assert all(abs(x - y) <= 1e-12 for x, y in zip(a, b)), (got, want)
+    assert sched2.get_last_lr() == [g["lr"] for g in opt2.param_groups]
+    assert scaler.state_dict()["_growth_tracker"] == 7
 
 
 def test_video_inference_loop(golden, msda_double):
