@@ -21,6 +21,7 @@ source text is stored.  Fixture <-> reference map:
   e2e_cfg1         BASELINE config #1 shapes: one frame, 256x256, 3 feature levels, 1 query
   train_step       one iteration of engine.train_one_epoch (engine.py:29-123) with main.py:76-99's optimizer: loss, gradient
                    norm, post-step parameters; ckpt_ref.pth = a checkpoint written by util.misc.save_on_master (main.py:229-236)
+  swin_n392        WindowAttention3D at the full (8,7,7) window, N = 392 (config #5), head_dim 32, with shift mask
   swin3d           Video-Swin pieces (video_swin_transformer.py) -- see gen_swin3d
 """
 import json
@@ -562,6 +563,26 @@ def gen_swin3d():
     save("swin3d", meta, **arrays)
 
 
+def gen_swin_n392():
+    """BASELINE config #5's attention shape: the FULL (8,7,7) window (N = 392 tokens, 8 frames >= window depth so no clamping,
+    video_swin_transformer.py:71-84), head_dim 32, with the shift mask of a (0,3,3) shift (compute_mask :316-329)."""
+    ref_import.install()
+    import models.video_swin_transformer as vs
+    wa = vs.WindowAttention3D(64, (8, 7, 7), 2, qkv_bias=True)
+    shp = synth.shapes_of(wa)
+    wa.load_state_dict(synth.synth_state_dict(shp, seed=13), strict=False)
+    mask = vs.compute_mask(8, 14, 14, (8, 7, 7), (0, 3, 3), "cpu")            # 4 windows
+    x = synth.rand("w392_x", (4, 392, 64)).requires_grad_(True)
+    arrays, meta = {}, {"shapes": shp}
+    for tag, m in (("nomask", None), ("mask", mask)):
+        y = wa(x, m)
+        g = torch.autograd.grad((y * synth.rand("w392_go", y.shape)).sum(), [x] + list(wa.parameters()))
+        arrays[f"{tag}_y"], arrays[f"{tag}_gx"] = y, g[0]
+        meta[f"{tag}_grad_norms"] = {k: float(gg.norm()) for (k, _), gg in zip(wa.named_parameters(), g[1:])}
+        arrays[f"{tag}_gtable"] = dict(zip([k for k, _ in wa.named_parameters()], g[1:]))["relative_position_bias_table"]
+    save("swin_n392", meta, **arrays)
+
+
 def gen_e2e_swin():
     """OCPG end to end with the Video-Swin backbone (tiny Swin configuration), train mode."""
     ref_import.install()
@@ -592,7 +613,7 @@ GENS = {"msda_testpy": gen_msda_testpy, "msda_cases": gen_msda_cases, "msda_modu
         "transformer": gen_transformer, "lfm": gen_lfm, "fusion": gen_fusion, "dynmask_mso": gen_dynmask_mso,
         "matcher_crit": gen_matcher_crit, "e2e_tiny": gen_e2e_tiny, "e2e_d32": gen_e2e_d32, "e2e_cfg1": gen_e2e_cfg1,
         "train_step": gen_train_step,
-        "swin3d": gen_swin3d, "e2e_swin": gen_e2e_swin}
+        "swin3d": gen_swin3d, "swin_n392": gen_swin_n392, "e2e_swin": gen_e2e_swin}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GENS)

@@ -133,3 +133,35 @@ def check_e2e_swin(g, dev, rtol=5e-4, atol=5e-5):
         if abs(n - v) > 2e-2 * abs(v) + 1e-4:
             bad.append((k, n, v))
     assert not bad, bad[:6]
+
+
+def check_window_attention_n392(g, dev, dtype=torch.float32, rtol=5e-4, atol=5e-5):
+    """Config #5's window: the full (8,7,7) = 392 tokens, head_dim 32, 4 shifted windows; fp32, or fp16 storage (the
+    reference's --amp) against the same fp32 vectors."""
+    import ocpg_amd.models.video_swin_transformer as vs
+    wa = vs.WindowAttention3D(64, (8, 7, 7), 2, qkv_bias=True)
+    _load(wa, g.meta["shapes"], 13)
+    wa.to(dev)
+    blk = vs.SwinTransformerBlock3D(64, 2, window_size=(8, 7, 7), shift_size=(4, 3, 3))
+    region = blk._plan(8, 14, 14, dev)[3]                                     # region ids of the 4 shifted windows
+    mask = vs.compute_mask(8, 14, 14, (8, 7, 7), (0, 3, 3), dev) if dev.type != "cuda" else None
+    x = synth.rand("w392_x", (4, 392, 64)).to(dev).requires_grad_(True)
+    go = synth.rand("w392_go", (4, 392, 64)).to(dev)
+    for tag, use_mask in (("nomask", False), ("mask", True)):
+        with torch.autocast(dev.type, dtype=dtype, enabled=dtype != torch.float32):
+            y = wa(x, mask if use_mask else None, region if use_mask else None)
+        grads = torch.autograd.grad((y.float() * go).sum(), [x] + list(wa.parameters()))
+        if dtype == torch.float32:
+            close(y, g[f"{tag}_y"], rtol, atol, f"n392 {tag} y")
+            close(grads[0], g[f"{tag}_gx"], rtol * 10, atol * 10, f"n392 {tag} gx")
+        else:       # 16-bit storage of q/k/v/out: norm-relative bounds
+            rel = lambda a, b: float((a.detach().float().cpu() - b).norm() / b.norm())    # noqa: E731
+            assert rel(y, g[f"{tag}_y"]) <= 5e-3, rel(y, g[f"{tag}_y"])
+            assert rel(grads[0], g[f"{tag}_gx"]) <= 1e-2, rel(grads[0], g[f"{tag}_gx"])
+        tol = 2e-3 if dtype == torch.float32 else 2e-2
+        for (k, _), gg in zip(wa.named_parameters(), grads[1:]):
+            ref = g.meta[f"{tag}_grad_norms"][k]
+            assert abs(gg.float().norm().item() - ref) <= tol * abs(ref) + 1e-5, (tag, k, gg.norm().item(), ref)
+            if "bias_table" in k:
+                if dtype == torch.float32:
+                    close(gg, g[f"{tag}_gtable"], rtol * 10, atol * 50, f"n392 {tag} bias-table grad")

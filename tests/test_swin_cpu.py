@@ -18,6 +18,10 @@ def test_window_attention_and_masks(golden):
     sc.check_window_attention(golden("swin3d"), CPU)
 
 
+def test_window_attention_full_window_n392(golden):
+    sc.check_window_attention_n392(golden("swin_n392"), CPU)
+
+
 def test_shifted_block_and_patch_merging(golden):
     sc.check_block_and_merging(golden("swin3d"), CPU)
 
