@@ -69,7 +69,7 @@ def synthetic_batch(n_clips, device, seed, roberta=False):
     return (lambda: NestedTensor(x.clone(), tag_rect_mask(mask.clone(), valid_hw))), text, targets
 
 
-def make_optimizer(model, args):
+def make_optimizer(model, args, fused=True):
     """AdamW with the reference's four name-based LR groups (main.py:76-99)."""
     def has(n, keys):
         return any(k in n for k in keys)
@@ -82,12 +82,22 @@ def make_optimizer(model, args):
         {"params": [p for n, p in named if has(n, args.lr_linear_proj_names)], "lr": args.lr * args.lr_linear_proj_mult},
     ]
     groups = [g for g in groups if g["params"]]
-    return torch.optim.AdamW(groups, lr=args.lr, weight_decay=args.weight_decay, fused=True)
+    return torch.optim.AdamW(groups, lr=args.lr, weight_decay=args.weight_decay, fused=fused)
+
+
+def wrap_ddp(model, local_rank=None):
+    """main.py:62's DistributedDataParallel, configured for this model: bucket views (no grad copy), 64-MB buckets (xGMI is
+    point-to-point: fewer, larger all-reduces), no unused-parameter search (every trainable parameter receives a gradient:
+    tests/test_ddp_gloo.py), no buffer broadcast (the only buffers are frozen BN statistics, identical on every rank; re-
+    broadcasting them would also invalidate FrozenBatchNorm2d's cached scale/shift).  local_rank None = CPU (gloo tests)."""
+    return torch.nn.parallel.DistributedDataParallel(model, device_ids=None if local_rank is None else [local_rank],
+                                                     gradient_as_bucket_view=True, bucket_cap_mb=64, find_unused_parameters=False,
+                                                     broadcast_buffers=False)
 
 
 def forward_backward(model, criterion, samples, text, targets, amp_dtype, num_boxes=None, keep=None, scaler=None):
     """engine.py:50-62 + backward: forward, criterion, weighted sum, backward (grads accumulate into .grad)."""
-    with torch.autocast(device_type="cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
+    with torch.autocast(device_type=samples.tensors.device.type, dtype=amp_dtype, enabled=amp_dtype is not None):
         out = model(samples, text, targets)
         if num_boxes is not None:
             out["num_boxes"] = num_boxes
@@ -106,6 +116,7 @@ class EagerStep:
     def __init__(self, model, ddp_model, criterion, optimizer, make_samples, text, targets, args, amp_dtype):
         self.__dict__.update(locals())
         self.scaler = torch.amp.GradScaler("cuda") if amp_dtype == torch.float16 else None
+        self.grad_norm = None           # pre-clip total gradient norm of the last step (device scalar)
 
     def __call__(self):
         self.optimizer.zero_grad(set_to_none=True)
@@ -114,7 +125,8 @@ class EagerStep:
         if self.scaler is not None:
             self.scaler.unscale_(self.optimizer)
         if self.args.clip_max_norm > 0:
-            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.args.clip_max_norm, error_if_nonfinite=False, foreach=True)
+            self.grad_norm = torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.args.clip_max_norm, error_if_nonfinite=False,
+                                                            foreach=True)
         if self.scaler is not None:
             self.scaler.step(self.optimizer)
             self.scaler.update()
@@ -432,11 +444,7 @@ def main():
     if step is None:
         ddp_model = model
         if world > 1:
-            # broadcast_buffers=False: the only buffers are the frozen BN statistics (identical on every rank, never
-            # updated); re-broadcasting them every step would also invalidate FrozenBatchNorm2d's cached scale/shift
-            ddp_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], gradient_as_bucket_view=True,
-                                                                  bucket_cap_mb=64, find_unused_parameters=False,
-                                                                  broadcast_buffers=False)
+            ddp_model = wrap_ddp(model, local_rank)
         step = EagerStep(model, ddp_model, criterion, optimizer, make_samples, text, targets, args, amp_dtype)
 
     def sync():

@@ -1,8 +1,10 @@
 """N>1 path on CPU: 2 ranks over gloo, DistributedDataParallel around the product model (MSDA op -> test double),
 each rank a different clip.  Checks (a) DDP-averaged gradients equal the average of the two single-process gradients
 (which also exercises the criterion's num_boxes all-reduce + /world_size), (b) every trainable parameter received a
-gradient, so find_unused_parameters=False (as bench.py uses) is legitimate; test_num_boxes_allreduce covers unequal
-valid-frame counts across ranks."""
+gradient, so find_unused_parameters=False (as bench.py uses) is legitimate; test_bench_eager_step_two_ranks drives
+bench.py's OWN step object (wrap_ddp's bucket-view gradients, make_optimizer's four LR groups, clip, AdamW) and checks
+the post-step parameters against a single-process replay; test_num_boxes_allreduce covers unequal valid-frame counts
+across ranks."""
 import os
 import socket
 import sys
@@ -110,6 +112,89 @@ def test_ddp_two_ranks_gloo():
         assert abs(a - want).max() <= 2e-4 * (abs(want).max() + 1e-12) + 1e-7, k
         n_checked += 1
     assert n_checked > 100
+
+
+def _bench_inputs(rank_clip, meta):
+    import cases
+    from ocpg_amd.models.text_encoder.text_encoder import PrecomputedText
+    from ocpg_amd.util.misc import NestedTensor
+    T, H, W = meta["T"], meta["H"], meta["W"]
+    x, mask, targets = cases.e2e_inputs(2, T, H, W, meta["nopad_sizes"])
+    sl = slice(rank_clip, rank_clip + 1)
+    f, s, m = cases.tiny_text(2)
+    return (lambda: NestedTensor(x[sl].clone(), mask[sl].clone())), PrecomputedText(f[sl], s[sl], m[sl]), targets[sl]
+
+
+def _bench_worker(rank, world, port, q):
+    _setup_paths()
+    torch.set_num_threads(2)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    from conftest import Golden
+    meta = Golden("e2e_tiny").meta
+    args, model, crit = _build(meta)
+    model.train(), crit.train()
+    crit.iter = 0
+    ddp = bench.wrap_ddp(model)                                  # the wrapper bench.py builds for --gpus N
+    opt = bench.make_optimizer(model, args, fused=False)
+    make_samples, text, targets = _bench_inputs(rank, meta)
+    step = bench.EagerStep(model, ddp, crit, opt, make_samples, text, targets, args, None)
+    loss = step()
+    # gradient_as_bucket_view: .grad tensors are views of the reducer's buckets and hold the AVERAGED, clipped gradients
+    q.put((rank, float(loss), float(step.grad_norm), {k: p.detach().numpy().copy() for k, p in model.named_parameters() if p.requires_grad}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_bench_eager_step_two_ranks():
+    """bench.py's EagerStep under a 2-rank gloo group == averaging the two clips' gradients in one process, clipping at
+    clip_max_norm and stepping the same four-group AdamW: post-step parameters identical on both ranks and equal to the replay."""
+    _setup_paths()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        r, loss, gn, params = q.get(timeout=500)
+        got[r] = (loss, gn, params)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert abs(got[0][1] - got[1][1]) <= 1e-5 * abs(got[0][1])            # same (global) gradient norm on both ranks
+    for k, a in got[0][2].items():
+        assert abs(a - got[1][2][k]).max() <= 1e-7 * (abs(a).max() + 1e-12) + 1e-10, k
+    # single-process replay
+    import bench
+    from conftest import Golden
+    meta = Golden("e2e_tiny").meta
+    args, model, crit = _build(meta)
+    singles = [_clip_grads(r, meta, model, crit)[0] for r in range(2)]
+    opt = bench.make_optimizer(model, args, fused=False)
+    for k, p in model.named_parameters():
+        if p.requires_grad:
+            p.grad = 0.5 * (singles[0][k] + singles[1][k])
+    norm = torch.nn.utils.clip_grad_norm_(model.parameters(), args.clip_max_norm, error_if_nonfinite=False)
+    assert abs(float(norm) - got[0][1]) <= 2e-4 * float(norm), (float(norm), got[0][1])
+    opt.step()
+    bad, n_el, n_off = [], 0, 0
+    for k, p in model.named_parameters():
+        if p.requires_grad:
+            want = p.detach().numpy()
+            d = abs(got[0][2][k] - want)
+            # AdamW's first step moves every element by ~lr * g / (|g| + eps): elements whose averaged gradient is at rounding
+            # level (|g| ~ eps = 1e-8) may land anywhere within +-lr; everything else must agree to a few 1e-7
+            off = (d > 2e-6)
+            n_el += d.size
+            n_off += int(off.sum())
+            if d.max() > 2.1e-4 or off.mean() > 0.02:
+                bad.append((k, float(d.max()), float(off.mean())))
+    assert not bad, bad[:5]
+    assert n_off <= 2e-3 * n_el, (n_off, n_el)
 
 
 def _nb_worker(rank, world, port, q):
