@@ -228,6 +228,24 @@ int ocpg_masked_ce_fwd_f32(const float* x, const float* w, const float* t, int L
 int ocpg_masked_ce_bwd_f32(const float* x, const float* w, const float* t, const float* gloss, int Lr, long long per_layer, float* gx,
                            void* stream);
 
+/* Multi-head attention against a SHORT key sequence (Lk <= 32, head_dim 32, H <= 8 with 256 % H == 0) -- replaces the
+ * softmax(q k^T * scale + key padding) v core of nn.MultiheadAttention as called by VisionLanguageFusionModule.forward
+ * (models/segmentation.py:103-113) and by the decoder layer's self-attention (models/deformable_transformer.py:323-326); the
+ * projections around it stay GEMMs.  q [Lq, B, H*32], k / v [Lk, B, H*32], out / dout / dq like q: row (l, b) of tensor X
+ * starts at X + (l * B + b) * ldX elements (the projections' own layout, any row stride).  key_pad [B, Lk] bytes, non-zero
+ * = ignore this key, or NULL.  pdrop: dropout on the attention weights (0 = off), mask from Philox(seed, offset) keyed on
+ * (row, head, key) -- the backward regenerates it.  lse [Lq, B, H] fp32 kept for the backward.  dk / dv [Lk, B, H*32] fp32 are
+ * ACCUMULATED into (caller zeroes them).  dtype 0 fp32 / 1 bf16 / 2 fp16 (storage; fp32 arithmetic).
+ * Returns -2000 when the shape is not served (the caller keeps its generic attention path). */
+int ocpg_attn_smallk_fwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv,
+                         const unsigned char* key_pad, float scale, int Lq, int B, int H, int hd, int Lk, float pdrop,
+                         unsigned long long seed, unsigned long long offset, void* out, long long ldo, float* lse, int dtype,
+                         void* stream);
+int ocpg_attn_smallk_bwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv,
+                         const unsigned char* key_pad, const void* dout, long long ldo, const float* lse, float scale, int Lq,
+                         int B, int H, int hd, int Lk, float pdrop, unsigned long long seed, unsigned long long offset, void* dq,
+                         long long lddq, float* dk, float* dv, int dtype, void* stream);
+
 /* library / build identification: returns e.g. "ocpg_hip gfx950 r1" */
 const char* ocpg_hip_version(void);
 

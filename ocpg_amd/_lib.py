@@ -51,6 +51,11 @@ SIGNATURES = {
     "ocpg_masked_ce_bwd_f32": [_vp] * 4 + [_int, ctypes.c_longlong, _vp, _vp],
     "ocpg_im2col3x3_nhwc": [_vp] + [_int] * 6 + [_vp, _int, _vp],
     "ocpg_col2im3x3_nhwc": [_vp] + [_int] * 6 + [_vp, _int, _vp],
+    "ocpg_attn_smallk_fwd": [_vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, ctypes.c_float] + [_int] * 5
+                            + [ctypes.c_float, ctypes.c_ulonglong, ctypes.c_ulonglong, _vp, ctypes.c_longlong, _vp, _int, _vp],
+    "ocpg_attn_smallk_bwd": [_vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, _vp, ctypes.c_longlong, _vp,
+                             ctypes.c_float] + [_int] * 5 + [ctypes.c_float, ctypes.c_ulonglong, ctypes.c_ulonglong, _vp, ctypes.c_longlong,
+                                                             _vp, _vp, _int, _vp],
     "ocpg_win_attn_fwd": [_vp, _vp, _vp, ctypes.c_float] + [_int] * 5 + [_vp, _vp, _int, _vp],
     "ocpg_win_attn_bwd": [_vp, _vp, _vp, _vp, ctypes.c_float] + [_int] * 5 + [_vp] * 6 + [_int, _vp],
 }

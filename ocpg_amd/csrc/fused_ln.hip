@@ -17,21 +17,12 @@
 #include <stdint.h>
 
 #include "../../include/ocpg_hip.h"
+#include "philox.h"
 
 namespace {
 
-// ---- Philox-4x32-10 ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint4 philox(uint2 key, uint4 c) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint32_t lo0 = 0xD2511F53u * c.x, hi0 = __umulhi(0xD2511F53u, c.x);
-    const uint32_t lo1 = 0xCD9E8D57u * c.z, hi1 = __umulhi(0xCD9E8D57u, c.z);
-    c = make_uint4(hi1 ^ c.y ^ key.x, lo1, hi0 ^ c.w ^ key.y, lo0);
-    key.x += 0x9E3779B9u;
-    key.y += 0xBB67AE85u;
-  }
-  return c;
-}
+using ocpg_dev::philox;
+
 // keep flags of the 4 elements starting at linear index idx4 * 4; thr = p * 2^32 (drop when rnd < thr)
 __device__ __forceinline__ void keep4(uint64_t seed, uint64_t offset, uint64_t idx4, uint32_t thr, float scale, float (&k)[4]) {
   if (thr == 0u) { k[0] = k[1] = k[2] = k[3] = 1.f; return; }

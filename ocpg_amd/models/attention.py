@@ -7,6 +7,9 @@ from torch import nn
 
 from . import amp_cache
 from .amp_cache import lookup
+from .ops.functions import attn_smallk_func
+
+HIP_SMALLK = True       # A/B switch: csrc/attn_smallk.hip for the short-key shapes (text gate, decoder self-attention)
 
 
 class MultiheadAttention(nn.Module):
@@ -27,6 +30,22 @@ class MultiheadAttention(nn.Module):
         Lk = key.shape[0]
         H, hd = self.num_heads, C // self.num_heads
         w, b = lookup(self.in_proj_weight), lookup(self.in_proj_bias)
+        if HIP_SMALLK and query.is_cuda and hd == 32 and Lk <= 32 and H <= 8:
+            # short key sequence: the attention core is one HIP kernel each way on the projections' own [L, B, C] layout
+            # (no head permutes, no additive-mask tensor, no flash-attention launch for <= 32 keys)
+            if query is key:
+                wqk, wv = w.split([2 * C, C])
+                bqk, bv = b.split([2 * C, C])
+                qk = F.linear(query, wqk, bqk)
+                q, k = qk[..., :C], qk[..., C:]
+            else:
+                wq, wk, wv = w.chunk(3)
+                bq, bk, bv = b.chunk(3)
+                q, k = F.linear(query, wq, bq), F.linear(key, wk, bk)
+            v = F.linear(value, wv, bv)
+            o = attn_smallk_func.attention(q, k, v, key_padding_mask, hd ** -0.5, H, self.dropout if self.training else 0.0)
+            if o is not None:
+                return self.out_proj(o)
         # split the packed projection ONCE (backward: one cat per parameter, not three zero-fill + copy + add chains)
         if query is key:        # decoder self-attention: q and k from the same input -> one GEMM
             wqk, wv = w.split([2 * C, C])

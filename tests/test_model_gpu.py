@@ -679,3 +679,81 @@ def test_bench_mode_against_fp32_reference(golden, dev):
     d = sorted(abs(gn[k] - v) / v for k, v in ref.items())
     assert d[len(d) // 2] <= 0.25, d[len(d) // 2]                                              # median, measured 0.12
     assert d[int(0.9 * len(d))] <= 1.0, d[int(0.9 * len(d))]                                   # the LFM gate gradients sit in the tail
+
+
+def _mha_core_reference(q, k, v, pad, scale, H, keep=None):
+    """softmax(q k^T * scale + key padding) [* keep] v in plain tensor ops on [L, B, C] inputs (fp32)."""
+    Lq, B, C = q.shape
+    Lk, hd = k.shape[0], C // H
+    qh, kh, vh = (t.float().reshape(t.shape[0], B, H, hd).permute(1, 2, 0, 3) for t in (q, k, v))      # [B,H,L,hd]
+    s = torch.matmul(qh, kh.transpose(-1, -2)) * scale
+    if pad is not None:
+        s = s.masked_fill(pad[:, None, None, :], float("-inf"))
+    p = s.softmax(-1)
+    if keep is not None:
+        p = p * keep
+    return torch.matmul(p, vh).permute(2, 0, 1, 3).reshape(Lq, B, C)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Lq,B,H,Lk,padded", [(19200, 2, 8, 9, False), (1237, 3, 8, 20, True), (5, 10, 8, 5, False), (300, 2, 2, 7, True),
+                                               (77, 1, 4, 32, True)])
+def test_small_key_attention_kernel(dev, dtype, Lq, B, H, Lk, padded):
+    """csrc/attn_smallk.hip (fusion gate: 19 200 x B tokens against <= ~20 text tokens; decoder self-attention: 5 x 5) against
+    the tensor-op formulation of nn.MultiheadAttention's core: output, dq, dk, dv; key padding (incl. a padded FIRST key);
+    strided q / k views as the packed q-k projection produces them."""
+    from ocpg_amd.models.ops.functions import attn_smallk_func as f
+    C = H * 32
+    g = torch.Generator(device="cpu").manual_seed(Lq + Lk)
+    qk = torch.randn(Lq, B, 2 * C, generator=g).to(dev).to(dtype)
+    q = qk[..., :C]                                                       # strided view (row stride 2C)
+    k = (torch.randn(Lk, B, C, generator=g) * 1.5).to(dev).to(dtype)
+    v = torch.randn(Lk, B, C, generator=g).to(dev).to(dtype)
+    go = torch.randn(Lq, B, C, generator=g).to(dev).to(dtype)
+    pad = None
+    if padded:
+        pad = torch.zeros(B, Lk, dtype=torch.bool, device=dev)
+        pad[0, Lk - 2:] = True
+        if B > 1:
+            pad[1, 0] = True
+    scale = 32 ** -0.5
+    res = []
+    for hip in (True, False):
+        qi, ki, vi = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
+        out = f.attention(qi, ki, vi, pad, scale, H) if hip else _mha_core_reference(qi, ki, vi, pad, scale, H).to(dtype)
+        assert out is not None
+        grads = torch.autograd.grad((out.float() * go.float()).sum(), (qi, ki, vi))
+        res.append([out.detach().float()] + [x.float() for x in grads])
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    for a, b_, name in zip(res[0], res[1], ("out", "dq", "dk", "dv")):
+        assert (a - b_).abs().max().item() <= tol * b_.abs().max().item() + 1e-6, (name, (a - b_).abs().max().item(), b_.abs().max().item())
+
+
+def test_small_key_attention_dropout(dev):
+    """Attention-weight dropout (decoder self-attention in training): the mask is a pure function of (seed, offset), keeps
+    ~1-p of the weights scaled by 1/(1-p), and the backward uses the SAME mask (recovered here with one-hot values)."""
+    from ocpg_amd.models.ops.functions import attn_smallk_func as f
+    Lq, B, H, Lk, p = 640, 3, 8, 5, 0.3
+    C = H * 32
+    g = torch.Generator(device="cpu").manual_seed(3)
+    q, k = torch.randn(Lq, B, C, generator=g).to(dev), torch.randn(Lk, B, C, generator=g).to(dev)
+    rng = (20240607, 11)
+    onehot = torch.zeros(Lk, B, H, 32, device=dev)
+    for j in range(Lk):
+        onehot[j, :, :, j] = 1.0
+    probs = f.attention(q, k, onehot.view(Lk, B, C), None, 32 ** -0.5, H, p, rng).view(Lq, B, H, 32)[..., :Lk]     # dropped weights
+    clean = f.attention(q, k, onehot.view(Lk, B, C), None, 32 ** -0.5, H, 0.0).view(Lq, B, H, 32)[..., :Lk]
+    keep = torch.where(probs != 0, torch.full_like(probs, 1 / (1 - p)), torch.zeros_like(probs))
+    assert torch.allclose(probs, clean * keep, rtol=1e-5, atol=1e-7)
+    assert abs((keep > 0).float().mean().item() - (1 - p)) < 0.02
+    assert torch.equal(probs, f.attention(q, k, onehot.view(Lk, B, C), None, 32 ** -0.5, H, p, rng).view(Lq, B, H, 32)[..., :Lk])
+    v = torch.randn(Lk, B, C, generator=g).to(dev)
+    go = torch.randn(Lq, B, C, generator=g).to(dev)
+    res = []
+    for hip in (True, False):
+        qi, ki, vi = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
+        out = f.attention(qi, ki, vi, None, 32 ** -0.5, H, p, rng) if hip else \
+            _mha_core_reference(qi, ki, vi, None, 32 ** -0.5, H, keep.permute(1, 2, 0, 3))
+        res.append([out.detach()] + list(torch.autograd.grad((out * go).sum(), (qi, ki, vi))))
+    for a, b_, name in zip(res[0], res[1], ("out", "dq", "dk", "dv")):
+        assert (a - b_).abs().max().item() <= 2e-5 * b_.abs().max().item() + 1e-6, name
