@@ -116,6 +116,17 @@ int ocpg_win_attn_bwd(const void* qkv, const float* bias, const float* biasT, co
 int ocpg_dynmask_fwd_f32(const float* feats, const float* params, const float* refpix, int BT, int Q, int C, int H, int W,
                          int stride, float* out, float* pre1, void* stream);
 
+/* Backward of the dynamic mask head (autograd of models/ocpg.py:505-549 in the reference), all decoder layers per launch.
+ * _pre: dout, pre1 [BT*Q,16,H,W] -> dpre [BT*Q,16,H,W] = (W1^T dout) * (pre1 > 0); part [BT*Q, ceil(HW/256), 320] per-strip
+ *       partial sums (dW1 16x16 | db0 | db1 | sum dpre*x | sum dpre*y); w0d [BT*Q,16,C] = the feature columns of W0, dense.
+ *       The two large contractions dW0 = dpre . feats^T and dfeat = W0^T . dpre are plain GEMMs on these buffers (ocpg_gemm).
+ * _fin: part + dw0 [BT*Q,16,C] (the dW0 GEMM's result) -> dparams [BT*Q, (C+2)*16+16*16+32] fully written in the reference's
+ *       parameter order (parse_dynamic_params, ocpg.py:552-569) and dref [BT*Q,2] (may be NULL). */
+int ocpg_dynmask_bwd_pre_f32(const float* dout, const float* pre1, const float* params, int BT, int Q, int C, int H, int W,
+                             int stride, float* dpre, float* part, float* w0d, void* stream);
+int ocpg_dynmask_bwd_fin_f32(const float* part, const float* params, const float* refpix, const float* dw0, int BT, int Q, int C,
+                             int H, int W, float* dparams, float* dref, void* stream);
+
 /* 3x3 convolution of channels-last maps as one dense GEMM -- replaces the conv kernels behind nn.Conv2d(k=3) in the ResNet
  * body (torchvision Bottleneck.conv2 via models/backbone.py:86-117) and the neck (models/ocpg.py:118-126); the GEMM itself
  * is hipBLASLt's.  Geometry: kernel 3x3, padding == dil, stride in {1,2}; Ho = (H-1)/stride + 1, Wo likewise.

@@ -27,6 +27,8 @@ SIGNATURES = {
     "ocpg_bn_act_fwd": [_vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _int, ctypes.c_longlong, _int, _int, _vp],
     "ocpg_bn_act_bwd": [_vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _int, ctypes.c_longlong, _int, _int, _vp],
     "ocpg_dynmask_fwd_f32": [_vp, _vp, _vp] + [_int] * 6 + [_vp, _vp, _vp],
+    "ocpg_dynmask_bwd_pre_f32": [_vp, _vp, _vp] + [_int] * 6 + [_vp, _vp, _vp, _vp],
+    "ocpg_dynmask_bwd_fin_f32": [_vp, _vp, _vp, _vp] + [_int] * 5 + [_vp, _vp, _vp],
     "ocpg_gemm": [_vp, _vp, _vp, _vp] + [_int] * 4 + [ctypes.c_longlong] * 10 + [ctypes.c_float, ctypes.c_float, _vp],
     "ocpg_gemm_plans": [],
     "ocpg_gemm_bn_act": [_vp] * 6 + [_int, _int] + [ctypes.c_longlong] * 3 + [_vp],

@@ -153,7 +153,129 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DYNMASK_WPE,
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Backward, everything that is not a large contraction, in two launches for all decoder layers:
+//   dynmask_bwd_pre:  per (query n, strip of 256 pixels): dh = W1^T dout, dpre = dh * (pre1 > 0) -> dpre [n,16,hw] (operand of
+//                     the two GEMMs dW0 = dpre f^T and dfeat = W0^T dpre, which stay hipBLASLt's), and the strip's partial
+//                     sums of dW1 = dout relu(pre1)^T (16x16), db1 = sum dout, db0 = sum dpre, sum dpre * (x, y)  -> part
+//                     [n, strips, 320]; strip 0 also packs the feature columns of W0 densely (A operand of the dfeat GEMM).
+//   dynmask_bwd_fin:  per query: strip sums -> the tail of dparams (dW1, db0, db1), the coordinate columns dwx / dwy =
+//                     ref * db0 - sum dpre * (x, y), dref = (W0[:,C] . db0, W0[:,C+1] . db0), and the placement of the dW0 GEMM's
+//                     result into the [16, C+2] rows of dparams.
+// The reference has no counterpart kernel: autograd differentiates the repeat / cat / two grouped conv2d of
+// models/ocpg.py:505-549 (a [1, b*t*q*(C+2), h, w] tensor per decoder layer).
+constexpr int BT_ = 256;      // pixels (= threads) per strip
+constexpr int TS = 257;       // LDS row stride of a [16][256] tile (floats): row reads by 16 lanes hit 16 different banks
+
+__global__ __launch_bounds__(BT_) void dynmask_bwd_pre(const float* __restrict__ dout, const float* __restrict__ pre1,
+                                                       const float* __restrict__ params, int C, int HW, int W, int stride, int strips,
+                                                       float* __restrict__ dpre, float* __restrict__ part, float* __restrict__ w0d) {
+  __shared__ float w1[CH * CH];
+  __shared__ float td[CH * TS], th[CH * TS], tp[CH * TS];      // dout, relu(pre1), dpre tiles of the strip
+  const long long n = blockIdx.y;
+  const int NW0 = (C + 2) * CH, NP = NW0 + CH * CH + 2 * CH;
+  const float* p = params + n * NP;
+  if (threadIdx.x < CH * CH) w1[threadIdx.x] = p[NW0 + threadIdx.x];          // W1[o2][o] at o2*16 + o
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < CH * C; i += BT_) w0d[n * CH * C + i] = p[(i / C) * (C + 2) + i % C];
+  __syncthreads();
+  const int px = blockIdx.x * BT_ + threadIdx.x;
+  const bool live = px < HW;
+  float go[CH], pr[CH];
+#pragma unroll
+  for (int o = 0; o < CH; ++o) {
+    go[o] = live ? dout[(n * CH + o) * HW + px] : 0.f;
+    pr[o] = live ? pre1[(n * CH + o) * HW + px] : 0.f;
+  }
+#pragma unroll
+  for (int o = 0; o < CH; ++o) {
+    float dh = 0.f;
+#pragma unroll
+    for (int o2 = 0; o2 < CH; ++o2) dh += w1[o2 * CH + o] * go[o2];
+    const float dp = pr[o] > 0.f ? dh : 0.f;
+    if (live) dpre[(n * CH + o) * HW + px] = dp;
+    td[o * TS + threadIdx.x] = go[o];
+    th[o * TS + threadIdx.x] = pr[o] > 0.f ? pr[o] : 0.f;
+    tp[o * TS + threadIdx.x] = dp;
+  }
+  __syncthreads();
+  // thread (a, o): dW1[a][o]; the a == 0 / 1 / 2 / 3 rows of threads also reduce db0 / db1 / sum dpre*x / sum dpre*y of channel o
+  const int a = threadIdx.x / CH, o = threadIdx.x % CH;
+  float acc = 0.f, extra = 0.f;
+  const int px0 = blockIdx.x * BT_;
+  for (int i = 0; i < BT_; ++i) {
+    acc += td[a * TS + i] * th[o * TS + i];
+    if (a < 4) {
+      const int pxi = min(px0 + i, HW - 1);
+      const float v = a == 1 ? td[o * TS + i] : tp[o * TS + i];
+      const float wgt = a < 2 ? 1.f : a == 2 ? (float)((pxi % W) * stride + stride / 2) : (float)((pxi / W) * stride + stride / 2);
+      extra += v * wgt;
+    }
+  }
+  float* out = part + (n * strips + blockIdx.x) * 320;
+  out[threadIdx.x] = acc;
+  if (a < 4) out[256 + a * CH + o] = extra;        // [db0 | db1 | momx | momy] x 16
+}
+
+__global__ __launch_bounds__(320) void dynmask_bwd_fin(const float* __restrict__ part, const float* __restrict__ params,
+                                                       const float* __restrict__ refpix, const float* __restrict__ dw0, int C, int strips,
+                                                       float* __restrict__ dparams, float* __restrict__ dref) {
+  __shared__ float s[320];
+  const long long n = blockIdx.x;
+  const int NW0 = (C + 2) * CH, NP = NW0 + CH * CH + 2 * CH;
+  float acc = 0.f;
+  for (int k = 0; k < strips; ++k) acc += part[(n * strips + k) * 320 + threadIdx.x];
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  float* dp = dparams + n * NP;
+  const float* p = params + n * NP;
+  const int t = threadIdx.x;
+  if (t < 256) dp[NW0 + t] = s[t];                                        // dW1
+  else if (t < 272) dp[NW0 + 256 + (t - 256)] = s[t];                     // db0
+  else if (t < 288) dp[NW0 + 272 + (t - 272)] = s[t];                     // db1
+  else if (t < 304) {                                                     // coordinate column x of W0 row o
+    const int o = t - 288;
+    dp[o * (C + 2) + C] = refpix[2 * n] * s[256 + o] - s[288 + o];
+  } else {
+    const int o = t - 304;
+    dp[o * (C + 2) + C + 1] = refpix[2 * n + 1] * s[256 + o] - s[304 + o];
+  }
+  if (dref && t < 2) {
+    float r = 0.f;
+    for (int o = 0; o < CH; ++o) r += p[o * (C + 2) + C + t] * s[256 + o];
+    dref[2 * n + t] = r;
+  }
+  for (int i = t; i < CH * C; i += 320) dp[(i / C) * (C + 2) + i % C] = dw0[n * CH * C + i];
+}
+
 }  // namespace
+
+extern "C" int ocpg_dynmask_bwd_pre_f32(const float* dout, const float* pre1, const float* params, int BT, int Q, int C, int H, int W,
+                                        int stride, float* dpre, float* part, float* w0d, void* stream) {
+  if (BT < 0 || Q <= 0 || C <= 0 || H <= 0 || W <= 0) return -1006;
+  if ((long long)BT * Q > 65535) return -1008;
+  if (BT == 0) return 0;
+  if (!dout) return -1001;
+  if (!pre1) return -1002;
+  if (!params) return -1003;
+  if (!dpre || !part || !w0d) return -1010;
+  const int HW = H * W, strips = (HW + BT_ - 1) / BT_;
+  dynmask_bwd_pre<<<dim3(strips, BT * Q), BT_, 0, (hipStream_t)stream>>>(dout, pre1, params, C, HW, W, stride, strips, dpre, part, w0d);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+extern "C" int ocpg_dynmask_bwd_fin_f32(const float* part, const float* params, const float* refpix, const float* dw0, int BT, int Q, int C,
+                                        int H, int W, float* dparams, float* dref, void* stream) {
+  if (BT < 0 || Q <= 0 || C <= 0 || H <= 0 || W <= 0) return -1006;
+  if (BT == 0) return 0;
+  if (!part || !params || !refpix || !dw0) return -1001;
+  if (!dparams) return -1010;
+  const int strips = (H * W + BT_ - 1) / BT_;
+  dynmask_bwd_fin<<<BT * Q, 320, 0, (hipStream_t)stream>>>(part, params, refpix, dw0, C, strips, dparams, dref);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
 
 extern "C" int ocpg_dynmask_fwd_f32(const float* feats, const float* params, const float* refpix, int BT, int Q, int C, int H, int W,
                                     int stride, float* out, float* pre1, void* stream) {

@@ -1,9 +1,9 @@
 """Dynamic mask head: autograd binding of ocpg_dynmask_fwd_f32 (csrc/dynmask.hip).
 
 Forward is the fused HIP kernel (coordinate channels + both per-query 1x1 convs, one pass over the features).  The
-backward is three batched GEMMs plus a handful of reductions on the saved layer-1 pre-activation -- every large
-contraction of the backward (dW0 = dpre . feats^T, dfeat = W0^T . dpre, dh = W1^T . dout) is GEMM-shaped and goes to
-hipBLASLt; no [b*t*q*(C+2), h, w] tensor is ever formed (models/ocpg.py:513-517 materialises 99 MB per call).
+backward is two HIP launches (dpre and every small reduction; assembly of dparams) plus the two large contractions
+(dW0 = dpre . feats^T, dfeat = W0^T . dpre) as hipBLASLt GEMMs; no [b*t*q*(C+2), h, w] tensor is ever formed
+(models/ocpg.py:513-517 materialises 99 MB per call).
 """
 import torch
 from torch.autograd import Function
@@ -37,33 +37,39 @@ class DynamicMaskFunction(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
+        """Two HIP launches (csrc/dynmask.hip: dpre + every small reduction; assembly of dparams / dref) around the two
+        GEMM-shaped contractions dW0 = dpre . feats^T and dfeat = W0^T . dpre (hipBLASLt through ocpg_gemm, written
+        straight into their destinations): 4 launches for all decoder layers, no intermediate of the reference's
+        [1, b*t*q*(C+2), h, w] size (models/ocpg.py:513-517)."""
         feats, params, refpix, pre1 = ctx.saved_tensors
         bt, c, h, w = feats.shape
         n, hw = params.shape[0], h * w
         q = n // bt
-        s = ctx.stride
-        dout = dout.float().reshape(n, CH, hw)
-        pre = pre1.view(n, CH, hw)
-        w0 = params[:, :(c + 2) * CH].view(n, CH, c + 2)
-        w1 = params[:, (c + 2) * CH:(c + 2) * CH + CH * CH].view(n, CH, CH)
-        hact = pre.clamp(min=0)
-        dw1 = torch.bmm(dout, hact.transpose(1, 2))                                   # [n,16,16]
-        db1 = dout.sum(-1)
-        dpre = torch.bmm(w1.transpose(1, 2), dout) * (pre > 0)                        # [n,16,hw]
-        db0 = dpre.sum(-1)                                                            # [n,16]
-        xs = (torch.arange(w, device=feats.device, dtype=torch.float32) * s + s // 2).repeat(h)
-        ys = (torch.arange(h, device=feats.device, dtype=torch.float32) * s + s // 2).repeat_interleave(w)
-        mom = torch.matmul(dpre, torch.stack([xs, ys], 1))                            # [n,16,2]: sum_px dpre * (x, y)
-        dwx = refpix[:, 0:1] * db0 - mom[..., 0]
-        dwy = refpix[:, 1:2] * db0 - mom[..., 1]
-        dref = torch.stack([(w0[..., c] * db0).sum(-1), (w0[..., c + 1] * db0).sum(-1)], -1) if ctx.needs_input_grad[2] else None
-        f = feats.view(bt, c, hw)
-        dpre_bt = dpre.view(bt, q * CH, hw)
-        dw0 = torch.bmm(dpre_bt, f.transpose(1, 2)).view(n, CH, c)                    # [n,16,C]
-        dfeat = None
-        if ctx.needs_input_grad[0]:
-            dfeat = torch.bmm(w0[..., :c].reshape(bt, q * CH, c).transpose(1, 2), dpre_bt).view(bt, c, h, w)
-        dparams = torch.cat([torch.cat([dw0, dwx[..., None], dwy[..., None]], -1).flatten(1), dw1.flatten(1), db0, db1], 1)
+        dev = feats.device
+        dout = dout.float().contiguous()
+        strips = (hw + 255) // 256
+        dpre = torch.empty((n, CH, hw), dtype=torch.float32, device=dev)
+        part = torch.empty((n, strips, 320), dtype=torch.float32, device=dev)
+        w0d = torch.empty((n, CH, c), dtype=torch.float32, device=dev)
+        dw0 = torch.empty((n, CH, c), dtype=torch.float32, device=dev)
+        dparams = torch.empty_like(params)
+        need_ref, need_feat = ctx.needs_input_grad[2], ctx.needs_input_grad[0]
+        dref = torch.empty((n, 2), dtype=torch.float32, device=dev) if need_ref else None
+        dfeat = torch.empty_like(feats) if need_feat else None
+        L = lib()
+        with torch.cuda.device(dev):
+            st = stream_ptr()
+            check(L.ocpg_dynmask_bwd_pre_f32(dout.data_ptr(), pre1.data_ptr(), params.data_ptr(), bt, q, c, h, w, ctx.stride, dpre.data_ptr(),
+                                             part.data_ptr(), w0d.data_ptr(), st), "ocpg_dynmask_bwd_pre_f32")
+            # dW0 [bt, q*16, C] = dpre [bt, q*16, hw] . feats^T (feats stored [C, hw] = B^T)
+            check(L.ocpg_gemm(dpre.data_ptr(), feats.data_ptr(), dw0.data_ptr(), None, 0, 0, 0, 1, q * CH, c, hw, hw, hw, c, bt,
+                              q * CH * hw, c * hw, q * CH * c, 1.0, 0.0, st), "ocpg_gemm (dynmask dW0)")
+            if need_feat:
+                # dfeat [bt, C, hw] = W0^T [C, q*16] . dpre [q*16, hw]  (W0 stored [q*16, C] = A^T)
+                check(L.ocpg_gemm(w0d.data_ptr(), dpre.data_ptr(), dfeat.data_ptr(), None, 0, 0, 1, 0, c, hw, q * CH, c, hw, hw, bt,
+                                  q * CH * c, q * CH * hw, c * hw, 1.0, 0.0, st), "ocpg_gemm (dynmask dfeat)")
+            check(L.ocpg_dynmask_bwd_fin_f32(part.data_ptr(), params.data_ptr(), refpix.data_ptr(), dw0.data_ptr(), bt, q, c, h, w,
+                                             dparams.data_ptr(), None if dref is None else dref.data_ptr(), st), "ocpg_dynmask_bwd_fin_f32")
         return dfeat, dparams, dref, None
 
 
