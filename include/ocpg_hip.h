@@ -136,6 +136,21 @@ int ocpg_dynmask_bwd_fin_f32(const float* part, const float* params, const float
 int ocpg_im2col3x3_nhwc(const void* x, int N, int H, int W, int C, int stride, int dil, void* cols, int dtype, void* stream);
 int ocpg_col2im3x3_nhwc(const void* dcols, int N, int H, int W, int C, int stride, int dil, void* dx, int dtype, void* stream);
 
+/* 3x3 convolution (padding 1, stride 1 | 2) of channels-last bf16 maps as an implicit GEMM on the matrix cores
+ * (csrc/conv3x3_mfma.hip: MFMA 32x32x16 bf16, fp32 accumulation, no im2col buffer) -- replaces the MIOpen kernels behind
+ * torchvision Bottleneck.conv2 (models/backbone.py:86-117) and, in its epilogue, FrozenBatchNorm2d's affine + ReLU
+ * (models/backbone.py:46-56).
+ *   fwd:   x [N,H,W,Cin], w [Cout,3,3,Cin] (a channels-last weight as it lies in memory) -> y [N,Ho,Wo,Cout] =
+ *          act(conv(x, w) * scale[co] + bias[co]); scale / bias fp32 or NULL; Cin % 32 == 0.
+ *   dgrad: dy [N,Ho,Wo,Cout], wT [Cin,3,3,Cout] (channel axes swapped, taps NOT flipped) -> dx [N,H,W,Cin] fully written;
+ *          Cout % 32 == 0.
+ * -2000: geometry not served (the caller keeps its other path).  The weight gradient is a GEMM over the im2col matrix
+ * (ocpg_im2col3x3_nhwc + ocpg_gemm). */
+int ocpg_conv3x3_mfma_fwd(const void* x, const void* w, const float* scale, const float* bias, int relu, int N, int H, int W,
+                          int Cin, int Cout, int stride, void* y, void* stream);
+int ocpg_conv3x3_mfma_dgrad(const void* dy, const void* wT, int N, int H, int W, int Cin, int Cout, int stride, void* dx,
+                            void* stream);
+
 /* Dense GEMM with a per-shape plan cache over hipBLASLt -- replaces the at::mm / at::addmm / at::bmm calls behind
  * nn.Linear and the 1x1 nn.Conv2d layers on the path (models/deformable_transformer.py:236-257,313-327 FFNs,
  * models/ops/modules/ms_deform_attn.py:63-66 projections, torchvision Bottleneck.conv1/conv3 via models/backbone.py) and

@@ -29,6 +29,8 @@ SIGNATURES = {
     "ocpg_dynmask_fwd_f32": [_vp, _vp, _vp] + [_int] * 6 + [_vp, _vp, _vp],
     "ocpg_dynmask_bwd_pre_f32": [_vp, _vp, _vp] + [_int] * 6 + [_vp, _vp, _vp, _vp],
     "ocpg_dynmask_bwd_fin_f32": [_vp, _vp, _vp, _vp] + [_int] * 5 + [_vp, _vp, _vp],
+    "ocpg_conv3x3_mfma_fwd": [_vp, _vp, _vp, _vp] + [_int] * 7 + [_vp, _vp],
+    "ocpg_conv3x3_mfma_dgrad": [_vp, _vp] + [_int] * 6 + [_vp, _vp],
     "ocpg_gemm": [_vp, _vp, _vp, _vp] + [_int] * 4 + [ctypes.c_longlong] * 10 + [ctypes.c_float, ctypes.c_float, _vp],
     "ocpg_gemm_plans": [],
     "ocpg_gemm_bn_act": [_vp] * 6 + [_int, _int] + [ctypes.c_longlong] * 3 + [_vp],

@@ -65,6 +65,7 @@ class FrozenBatchNorm2d(nn.Module):
 
 
 FUSED_CONV_BN = os.environ.get("OCPG_FUSED_CONV_BN", "1") != "0"     # A/B switch
+MFMA_CONV3X3 = os.environ.get("OCPG_MFMA_CONV3X3", "1") != "0"     # A/B switch: 3x3 conv + BN + ReLU by csrc/conv3x3_mfma.hip (bf16, >= 128 channels)
 FUSED_CONV3X3_BN = os.environ.get("OCPG_FUSED_CONV3X3_BN", "0") != "0"     # opt-in: 3x3 conv + BN + ReLU as im2col + epilogue GEMM (small maps); measured neutral in the step
 
 
@@ -78,6 +79,13 @@ def conv_bn_act(conv, bn, x, skip, relu):
             scale, shift = bn.scale_shift()
             n, _, h, wd = x.shape
             return conv_bn_func.conv1x1_bn_act(x, w, scale, shift, skip, relu, amp_cache._split_rows(n * h * wd) if amp_cache.SPLIT_K else 1)
+    if MFMA_CONV3X3 and skip is None and conv_bn_func.eligible3x3_mfma(x, conv):
+        w = amp_cache.lookup(conv.weight)
+        if w.dtype == x.dtype:
+            scale, shift = bn.scale_shift()
+            s = conv.stride[0]
+            rows = x.shape[0] * ((x.shape[2] - 1) // s + 1) * ((x.shape[3] - 1) // s + 1)
+            return conv_bn_func.conv3x3_mfma_bn_act(x, w, scale, shift, relu, s, amp_cache._split_rows(rows) if amp_cache.SPLIT_K else 1)
     if FUSED_CONV3X3_BN and skip is None and conv_bn_func.eligible3x3(x, conv):
         w = amp_cache.lookup(conv.weight)
         if w.dtype == x.dtype:

@@ -182,3 +182,74 @@ class Conv3x3BNAct(Function):
 
 def conv3x3_bn_act(x, w, scale, shift, relu, stride, dil, splits):
     return Conv3x3BNAct.apply(x, w, scale, shift, relu, int(stride), int(dil), splits)
+
+
+# ---- 3x3 conv (padding 1, stride 1|2) + frozen BN + ReLU on the matrix cores: csrc/conv3x3_mfma.hip ------------------------
+def eligible3x3_mfma(x, conv):
+    """bf16 channels-last map, 3x3 / padding 1 / dilation 1 / stride 1|2 / no bias, channel counts the kernel's K step and its
+    128-wide output tile serve well (>= 128: ResNet layers 2-4; the 64-channel layer1 keeps MIOpen)."""
+    return (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and conv.kernel_size == (3, 3) and conv.groups == 1
+            and conv.bias is None and conv.stride[0] == conv.stride[1] and conv.stride[0] in (1, 2) and conv.dilation == (1, 1)
+            and conv.padding == (1, 1) and conv.padding_mode == "zeros" and x.is_contiguous(memory_format=_CL)
+            and x.shape[1] % 64 == 0 and conv.out_channels % 64 == 0 and x.shape[1] >= 128 and conv.out_channels >= 128)
+
+
+class Conv3x3MfmaBNAct(Function):
+    """y = act(bn(conv3x3(x))): ONE launch forward (implicit-GEMM MFMA kernel with the frozen-BN affine + ReLU in its epilogue).
+    Backward: frozen-BN/ReLU backward (HIP) -> input gradient by the same MFMA kernel on the channel-swapped weight ->
+    weight gradient as im2col (HIP) + hipBLASLt GEMM over the rows (split for occupancy)."""
+
+    @staticmethod
+    def forward(ctx, x, w, scale, shift, relu, stride, splits):
+        n, c, h, wd = x.shape
+        co = w.shape[0]
+        ho, wo = (h - 1) // stride + 1, (wd - 1) // stride + 1
+        w2 = w.permute(0, 2, 3, 1)                                   # [co,3,3,c]: a view when the weight is channels-last
+        if not w2.is_contiguous():
+            w2 = w2.contiguous()
+        y = torch.empty((n, co, ho, wo), dtype=x.dtype, device=x.device, memory_format=_CL)
+        st = torch.cuda.current_stream().cuda_stream
+        check(lib().ocpg_conv3x3_mfma_fwd(x.data_ptr(), w2.data_ptr(), scale.data_ptr(), shift.data_ptr(), int(relu), n, h, wd, c, co, stride,
+                                          y.data_ptr(), st), "ocpg_conv3x3_mfma_fwd")
+        ctx.save_for_backward(x, w2, y, scale)
+        ctx.meta = (bool(relu), splits, stride)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, w2, y, scale = ctx.saved_tensors
+        relu, splits, stride = ctx.meta
+        n, c, h, wd = x.shape
+        co, ho, wo = y.shape[1], y.shape[2], y.shape[3]
+        m, k = n * ho * wo, 9 * c
+        L = lib()
+        st = torch.cuda.current_stream().cuda_stream
+        if gy.dtype != y.dtype or not gy.is_contiguous(memory_format=_CL):
+            gy = gy.to(y.dtype).contiguous(memory_format=_CL)
+        gz = torch.empty_like(y)
+        check(L.ocpg_bn_act_bwd(gy.data_ptr(), y.data_ptr(), scale.data_ptr(), gz.data_ptr(), None, m, co, 1, int(relu), 1, st), "ocpg_bn_act_bwd")
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            wt = w2.permute(3, 1, 2, 0).contiguous()               # [c,3,3,co]
+            gx = torch.empty((n, c, h, wd), dtype=y.dtype, device=y.device, memory_format=_CL)
+            check(L.ocpg_conv3x3_mfma_dgrad(gz.data_ptr(), wt.data_ptr(), n, h, wd, c, co, stride, gx.data_ptr(), st), "ocpg_conv3x3_mfma_dgrad")
+        if ctx.needs_input_grad[1]:
+            cols = torch.empty((m, k), dtype=y.dtype, device=y.device)
+            check(L.ocpg_im2col3x3_nhwc(x.data_ptr(), n, h, wd, c, stride, 1, cols.data_ptr(), 1, st), "ocpg_im2col3x3_nhwc")
+            if splits > 1 and m % splits == 0:
+                r = m // splits
+                part = torch.empty((splits, co, k), dtype=y.dtype, device=y.device)
+                check(L.ocpg_gemm(gz.data_ptr(), cols.data_ptr(), part.data_ptr(), None, 1, 1, 1, 0, co, k, r, co, k, k, splits, r * co, r * k,
+                                  co * k, 1.0, 0.0, st), "ocpg_gemm")
+                g2 = part.sum(0)
+            else:
+                g2 = torch.empty((co, k), dtype=y.dtype, device=y.device)
+                check(L.ocpg_gemm(gz.data_ptr(), cols.data_ptr(), g2.data_ptr(), None, 1, 1, 1, 0, co, k, m, co, k, k, 1, 0, 0, 0, 1.0, 0.0, st),
+                      "ocpg_gemm")
+            gw = g2.view(co, 3, 3, c).permute(0, 3, 1, 2)          # channels-last strides of [co, c, 3, 3]
+        return gx, gw, None, None, None, None, None
+
+
+def conv3x3_mfma_bn_act(x, w, scale, shift, relu, stride, splits):
+    return Conv3x3MfmaBNAct.apply(x, w, scale, shift, relu, int(stride), splits)

@@ -757,3 +757,35 @@ def test_small_key_attention_dropout(dev):
         res.append([out.detach()] + list(torch.autograd.grad((out * go).sum(), (qi, ki, vi))))
     for a, b_, name in zip(res[0], res[1], ("out", "dq", "dk", "dv")):
         assert (a - b_).abs().max().item() <= 2e-5 * b_.abs().max().item() + 1e-6, name
+
+
+@pytest.mark.parametrize("n,c,co,h,w,stride", [(10, 256, 256, 24, 40, 1), (2, 128, 128, 48, 80, 1), (3, 256, 256, 48, 80, 2),
+                                                (2, 512, 512, 12, 20, 1), (1, 128, 256, 7, 9, 2), (2, 192, 320, 5, 6, 1)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_conv3x3_mfma_kernel(dev, n, c, co, h, w, stride, relu):
+    """csrc/conv3x3_mfma.hip (implicit-GEMM bf16 MFMA 3x3 conv + frozen-BN affine + ReLU in the epilogue, its input-gradient
+    twin, im2col + GEMM weight gradient) against F.conv2d in fp32 on the same bf16-rounded operands followed by the affine:
+    ResNet-101 layer2/3/4 shapes incl. the stride-2 blocks, a ragged map (tiles with masked rows) and channel counts that are
+    not multiples of the 128-wide output tile."""
+    from ocpg_amd.models.ops.functions import conv_bn_func as f
+    g = torch.Generator(device="cpu").manual_seed(n * 1000 + c + h)
+    x = torch.randn(n, c, h, w, generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(co, c, 3, 3, generator=g) * (2.0 / (9 * c)) ** 0.5).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    scale = (torch.rand(co, generator=g) + 0.5).to(dev)
+    shift = (torch.randn(co, generator=g) * 0.1).to(dev)
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    go = torch.randn(n, co, ho, wo, generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    xi, wi = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    y = f.conv3x3_mfma_bn_act(xi, wi, scale, shift, relu, stride, 1)
+    assert y.shape == (n, co, ho, wo) and y.is_contiguous(memory_format=torch.channels_last)
+    gx, gw = torch.autograd.grad(y, (xi, wi), go)
+    xr, wr = x.float().requires_grad_(True), wt.float().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, wr, None, stride, 1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    yr = yr.relu() if relu else yr
+    # the backward of the product starts from the bf16-ROUNDED forward output's ReLU mask; use the same mask for the reference
+    gxr, gwr = torch.autograd.grad(yr, (xr, wr), go.float())
+    rel = lambda a, b: float((a.float() - b).norm() / (b.norm() + 1e-20))      # noqa: E731
+    assert rel(y, yr) <= 6e-3, rel(y, yr)                                     # bf16 output rounding: 2^-9 relative per element
+    assert rel(gx, gxr) <= 1.5e-2, rel(gx, gxr)
+    assert rel(gw, gwr) <= 1.5e-2, rel(gw, gwr)
+    assert (y.float() - yr).abs().max().item() <= 2e-2 * yr.abs().max().item() + 1e-3
