@@ -135,22 +135,6 @@ class EagerStep:
         return loss
 
 
-class _KeepEveryTensor(torch.utils._python_dispatch.TorchDispatchMode):
-    """Holds a reference to every tensor any op produces while active (forward and the autograd thread alike), so that NO
-    block of the graph's private pool is freed and re-used inside the capture.  Re-use inside a captured graph is what
-    goes wrong on replay on ROCm 7.2; with 288 GB of HBM the extra residency (every intermediate of
-    one forward+backward, a few tens of GB) is affordable."""
-
-    def __init__(self):
-        super().__init__()
-        self.keep = []
-
-    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
-        out = func(*args, **(kwargs or {}))
-        torch.utils._pytree.tree_map_only(torch.Tensor, self.keep.append, out)
-        return out
-
-
 class GraphStep:
     """Same step with forward + criterion + backward captured once into a HIP graph and replayed (launch-bound inner
     loop: ~9 500 kernels per step).  Outside the graph, per step: copy the batch into the static input buffers, the
@@ -160,12 +144,20 @@ class GraphStep:
         from ocpg_amd.util.misc import NestedTensor
         self.model, self.criterion, self.optimizer, self.args, self.world = model, criterion, optimizer, args, world
         self.make_samples, self.targets = make_samples, targets
+        self.fence = os.environ.get("OCPG_GRAPH_FENCE") == "1"       # diagnostic: host syncs around every replay
         first = make_samples()
         self.x, self.mask = first.tensors.clone(), first.mask.clone()
         self.num_boxes = criterion.global_num_boxes(targets, self.x.device).clone()
         criterion.iter_device = torch.zeros((), device=self.x.device)       # the criterion's call counter, device-resident
         self.calls_per_fwd = args.dec_layers
         self.params = [p for p in model.parameters() if p.requires_grad]
+        # AccumulateGrad nodes remember the stream they were created on and are handed from one autograd graph to the next for
+        # as long as ANY graph is alive (a parameter only holds a weak reference).  An earlier eager step on the default stream
+        # whose graph is still reachable through a reference cycle would therefore pull the NULL stream into the capture
+        # (cross-stream gradient accumulation) and hipStreamEndCapture segfaults on it.  Drop such graphs first.
+        import gc
+        criterion._last = None
+        gc.collect()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -175,17 +167,22 @@ class GraphStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         optimizer.zero_grad(set_to_none=True)
-        self.graph = torch.cuda.CUDAGraph()
-        # The captured step's outputs (model outputs, the 36 losses and through them the autograd graph) stay referenced
-        # for the lifetime of the graph.  Measured on ROCm 7.2 / torch 2.10: letting them die inside the capture made
-        # the THIRD replay return NaN gradients (tools/dbg_graph2.py, KEEP=... bisect); with them alive replays match
-        # eager.  self.check() compares a replay against an eager step before the timed region.
+        self.graph = torch.cuda.CUDAGraph(keep_graph=True)      # instantiated below, after the memset nodes are repaired
+        # The captured step's outputs (model outputs, the 36 losses) stay referenced for the lifetime of the graph (static
+        # outputs); self.check() compares a replay against an eager step before the timed region.
         self.static = {}
-        keeper = _KeepEveryTensor()
-        with torch.cuda.graph(self.graph), keeper:
+        # capture on the warm-up stream: the library's hipBLASLt workspace is per (device, stream) and was allocated there
+        # (a hipMalloc inside the capture would invalidate it)
+        with torch.cuda.graph(self.graph, stream=side):
             self.loss = forward_backward(model, criterion, NestedTensor(self.x.clone(), self.mask.clone()), text, targets, amp_dtype,
                                          self.num_boxes, keep=self.static)
-        self._alive = keeper.keep
+        # memset nodes (torch's reduction semaphores) replay with a corrupted pattern on this ROCm: swap them for kernel nodes
+        import ctypes
+        from ocpg_amd import _lib
+        n_fixed = ctypes.c_int(0)
+        _lib.check(_lib.lib().ocpg_graph_replace_memsets(self.graph.raw_cuda_graph(), ctypes.byref(n_fixed)), "ocpg_graph_replace_memsets")
+        self.memset_nodes_replaced = n_fixed.value
+        self.graph.instantiate()
         self.grads = [p.grad for p in self.params]
         assert all(g is not None for g in self.grads), "a trainable parameter received no gradient"
         self.flat = None
@@ -204,12 +201,11 @@ class GraphStep:
         s = self.make_samples()
         self.x.copy_(s.tensors), self.mask.copy_(s.mask)
         self.num_boxes.copy_(self.criterion.global_num_boxes(self.targets, self.x.device))
-        # Host-side fences around the replay: on ROCm 7.2 a replay that is merely stream-ordered against the eager
-        # optimizer kernels before/after it produced NaN gradients after a few steps (tools/dbg_graph2.py: stable with a
-        # synchronize per iteration, unstable without).  Two stream syncs cost ~50 us of a ~70 ms step.
-        torch.cuda.synchronize()
+        if self.fence:
+            torch.cuda.synchronize()
         self.graph.replay()
-        torch.cuda.synchronize()
+        if self.fence:
+            torch.cuda.synchronize()
         self.criterion.iter_device += self.calls_per_fwd
         if self.world > 1:
             flat = torch._utils._flatten_dense_tensors(self.grads)

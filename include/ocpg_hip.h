@@ -272,6 +272,12 @@ int ocpg_attn_smallk_bwd(const void* q, long long ldq, const void* k, long long 
                          int B, int H, int hd, int Lk, float pdrop, unsigned long long seed, unsigned long long offset, void* dq,
                          long long lddq, float* dk, float* dv, int dtype, void* stream);
 
+/* Whole-step HIP-graph capture support (no reference counterpart: the reference launches eagerly).  Replaces every memset node of
+ * a captured, not yet instantiated hipGraph_t by a kernel node with the same destination, value, extent and edges: with the HIP
+ * runtime of ROCm 7.x a captured hipMemsetAsync writes a stale pattern from the second launch of the instantiated graph on
+ * (csrc/graph_util.hip).  *n_replaced (may be NULL) receives the number of nodes rewritten. */
+int ocpg_graph_replace_memsets(void* hip_graph, int* n_replaced);
+
 /* library / build identification: returns e.g. "ocpg_hip gfx950 r1" */
 const char* ocpg_hip_version(void);
 

@@ -26,6 +26,7 @@
 #include <stdint.h>
 
 #include "../../include/ocpg_hip.h"
+#include "fill.h"
 
 namespace {
 
@@ -228,7 +229,7 @@ int ocpg_levelset_fwd_f32(const float* x, const float* feats, const float* box, 
   hipStream_t st = (hipStream_t)stream;
   const int hw = h * w;
   const int nblk = (hw + 256 * PPT - 1) / (256 * PPT);
-  hipError_t e = hipMemsetAsync(loss, 0, sizeof(float) * (size_t)Lr, st);
+  hipError_t e = ocpg_fill::zero_async(loss, sizeof(float) * (size_t)Lr, st);
   if (e != hipSuccess) return -(int)e;
   levelset_sums<<<dim3(nblk, N, Lr), 256, 0, st>>>(x, feats, box, N, C, CF, h, w, sums);
   levelset_final<<<dim3(N, Lr), 64, 0, st>>>(sums, nblk, N, C, coef, loss);

@@ -11,6 +11,7 @@
 #include <stdint.h>
 
 #include "../../include/ocpg_hip.h"
+#include "fill.h"
 
 namespace {
 
@@ -119,7 +120,7 @@ extern "C" int ocpg_matcher_cost_f32(const float* logits, const float* boxes, co
   if (!sums || !cost) return -1010;
   if ((long long)B * Lr > 65535 || Q > 65535) return -1007;
   hipStream_t s_ = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(sums, 0, sizeof(float) * 4 * (size_t)Lr * B * Q, s_);
+  hipError_t e = ocpg_fill::zero_async(sums, sizeof(float) * 4 * (size_t)Lr * B * Q, s_);
   if (e != hipSuccess) return -(int)e;
   const long long total = (long long)T * h * w;
   const unsigned split = (unsigned)((total + 256 * 16 - 1) / (256 * 16) < 64 ? (total + 256 * 16 - 1) / (256 * 16) : 64);   // >= 16 px per lane

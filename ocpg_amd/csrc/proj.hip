@@ -21,6 +21,7 @@
 #include <stdint.h>
 
 #include "../../include/ocpg_hip.h"
+#include "fill.h"
 
 namespace {
 
@@ -210,7 +211,7 @@ int ocpg_proj_fwd_f32(const float* x, const float* tcmax, const float* trmax, co
   if (!tcmax || !trmax || !tcmean || !trmean) return -1002;
   if (!colstat || !rowstat || !IU || !loss) return -1010;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(loss, 0, sizeof(float) * Lr, st);
+  hipError_t e = ocpg_fill::zero_async(loss, sizeof(float) * Lr, st);
   if (e != hipSuccess) return -(int)e;
   proj_col_stats<<<dim3((W + 63) / 64, (unsigned)F), 256, 0, st>>>(x, H, W, colstat);
   proj_row_stats<<<(unsigned)((F * H + 3) / 4), 256, 0, st>>>(x, (int)F, H, W, rowstat);

@@ -89,22 +89,37 @@ class _CastPlan:
         prefix = [0]
         for i in idx:
             prefix.append(prefix[-1] + (self.numels[i] + _CHUNK - 1) // _CHUNK)
-        ring = self.__dict__.get("_ring")
-        if ring is None:
-            cap = len(self.numels)
-            ring = self._ring = {"host": [torch.empty((4, cap), dtype=torch.int64).pin_memory() for _ in range(8)],
-                                 "dev": [torch.empty((4, cap), dtype=torch.int64, device=self.device) for _ in range(8)],
-                                 "event": [None] * 8, "next": 0}
-        k = ring["next"]
-        ring["next"] = (k + 1) % 8
-        if ring["event"][k] is not None:
-            ring["event"][k].synchronize()          # slot still in flight only if the host is 8 backward passes ahead
-        host, dev = ring["host"][k], ring["dev"][k]
-        host[:, :n] = torch.tensor([[grads[i].data_ptr() for i in idx], [base + 4 * self.offsets[i] for i in idx],
-                                    [self.numels[i] for i in idx], prefix[:-1]], dtype=torch.int64)
-        dev.copy_(host, non_blocking=True)
-        ev = ring["event"][k] = torch.cuda.Event()
-        ev.record()
+        table = torch.tensor([[grads[i].data_ptr() for i in idx], [base + 4 * self.offsets[i] for i in idx],
+                              [self.numels[i] for i in idx], prefix[:-1]], dtype=torch.int64)
+        if torch.cuda.is_current_stream_capturing():
+            # a captured host->device copy re-reads its HOST source on every replay: give this capture its own pinned table,
+            # alive as long as the plan (the ring below is overwritten by later eager steps); the pointers it holds are the
+            # graph's private-pool addresses, identical on every replay
+            spares = self.__dict__.get("_capture_spares")
+            if not spares:
+                raise RuntimeError("fused gradient cast: run one eager backward before capturing (pinned tables are allocated there)")
+            host = spares.pop()                                  # pinned memory cannot be allocated while capturing
+            dev = torch.empty((4, len(self.numels)), dtype=torch.int64, device=self.device)
+            self.__dict__.setdefault("_capture_tables", []).append((host, dev))
+            host[:, :n] = table
+            dev.copy_(host, non_blocking=True)
+        else:
+            ring = self.__dict__.get("_ring")
+            if ring is None:
+                cap = len(self.numels)
+                ring = self._ring = {"host": [torch.empty((4, cap), dtype=torch.int64).pin_memory() for _ in range(8)],
+                                     "dev": [torch.empty((4, cap), dtype=torch.int64, device=self.device) for _ in range(8)],
+                                     "event": [None] * 8, "next": 0}
+                self._capture_spares = [torch.empty((4, cap), dtype=torch.int64).pin_memory() for _ in range(4)]
+            k = ring["next"]
+            ring["next"] = (k + 1) % 8
+            if ring["event"][k] is not None:
+                ring["event"][k].synchronize()          # slot still in flight only if the host is 8 backward passes ahead
+            host, dev = ring["host"][k], ring["dev"][k]
+            host[:, :n] = table
+            dev.copy_(host, non_blocking=True)
+            ev = ring["event"][k] = torch.cuda.Event()
+            ev.record()
         # the last prefix entry (the total) is passed by value; the kernel's search never reads chunk_prefix[n]
         check(lib().ocpg_multi_cast(dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), dev[3].data_ptr(), n, prefix[-1],
                                     _DT[self.low_dtype], 0, torch.cuda.current_stream().cuda_stream), "ocpg_multi_cast")

@@ -282,6 +282,7 @@ class SetCriterion(nn.Module):
         if last is None or last[0] is not loss_dict:
             return sum(loss_dict[k] * self.weight_dict[k] for k in loss_dict if k in self.weight_dict)
         _, table, names = last
+        self._last = None       # consumed: a graph kept alive here would hand its AccumulateGrad nodes (and their stream) to the next step
         key = (tuple(map(tuple, names)), str(table.device))
         cache = self.__dict__.setdefault("_weight_tables", {})
         w = cache.get(key)
