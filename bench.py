@@ -362,11 +362,11 @@ def main():
                     help="features: random [B,9,768] text features (configs #1-#4); roberta: captions through RoBERTa-base (config #5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--graph", action="store_true",
-                    help="EXPERIMENTAL: replay forward+criterion+backward as one HIP graph. Off by default: on ROCm 7.2 / "
-                         "torch 2.10 replays turn non-finite after the first optimizer step unless extra tensors are kept "
-                         "alive (memory-reuse hazard inside the captured graph, see DESIGN.md section 5); the self-check below "
-                         "falls back to eager when that happens.")
+    ap.add_argument("--eager", action="store_true",
+                    help="launch every kernel eagerly (DistributedDataParallel for N > 1).  Default: forward + criterion + backward "
+                         "replayed as ONE HIP graph (the eager step is host-bound: ~3 100 launches, 59 ms vs 51.6 ms); the graph is "
+                         "checked against an eager step before the timed region and bench.py falls back to eager if that fails.")
+    ap.add_argument("--graph", action="store_true", help="(default since round 2; kept for old command lines)")
     a = ap.parse_args()
     T_FRAMES, HEIGHT, WIDTH = a.frames, a.height, a.width
 
@@ -411,7 +411,7 @@ def main():
     amp_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}[a.dtype]
     make_samples, text, targets = synthetic_batch(a.clips_per_gpu, device, seed=42 + rank, roberta=a.text == "roberta")
     step, mode = None, "eager"
-    if a.graph:
+    if not a.eager and amp_dtype != torch.float16:       # fp16 needs the GradScaler's host-side skip logic: eager
         snapshot = {k: v.clone() for k, v in model.state_dict().items()}
         try:
             torch.manual_seed(1234 + rank)
@@ -474,16 +474,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = t.item()
     kt = msda_fn.collect_kernel_timing() if (not a.no_kernel_timing and mode == "eager") else {}
-    lib_kt, lib_steps = {}, 3
-    if not a.no_kernel_timing and mode == "eager" and rank == 0 and world == 1:
-        # every other library call, timed over a few EXTRA steps outside the timed region (an event pair around each of
-        # ~500 calls per step costs host time in a launch-bound step: measured +20 ms per step)
+    lib_kt, lib_steps, kt_steps = {}, 3, a.steps
+    if not a.no_kernel_timing and rank == 0 and world == 1:
+        # per-kernel HIP-event timing of every library call over a few EXTRA eager steps outside the timed region, same
+        # process, same tensors (an event pair around each of ~500 calls per step costs host time: +20 ms per eager step; a
+        # graph replay cannot carry events at all, so in graph mode the MSDeformAttn kernels are timed here as well)
+        estep = step if mode == "eager" else EagerStep(model, model, criterion, optimizer, make_samples, text, targets, args, amp_dtype)
+        if mode != "eager":
+            msda_fn.enable_kernel_timing(True)
         _lib.enable_kernel_timing(True)
         for _ in range(lib_steps):
-            step()
+            estep()
         lib_kt = _lib.collect_kernel_timing(lib_work)
-    if not a.no_kernel_timing and mode != "eager" and rank == 0:
-        kt = time_msda_kernels(a.clips_per_gpu * T_FRAMES, device)
+        if mode != "eager":
+            kt, kt_steps = msda_fn.collect_kernel_timing(), lib_steps
+            msda_fn.enable_kernel_timing(False)
+    elif not a.no_kernel_timing and mode != "eager" and rank == 0:
+        kt = time_msda_kernels(a.clips_per_gpu * T_FRAMES, device)       # N > 1: the other ranks cannot join extra eager steps
 
     clips = a.steps * a.clips_per_gpu * world
     line = {
@@ -498,9 +505,11 @@ def main():
                            else "10-word captions through a random-init RoBERTa-base (frozen)", "launch": mode},
         "final_loss": float(loss.detach()),
     }
+    if mode != "eager":
+        line["hipgraph"] = {"memset_nodes_replaced_by_kernel_nodes": step.memset_nodes_replaced, "checked_against_eager": True}
     line["ranks"] = {"world_size": dist.get_world_size() if world > 1 else 1, "backend": dist.get_backend() if world > 1 else None}
     if rank == 0:
-        rows = kernel_table(kt, lib_kt, a.clips_per_gpu * T_FRAMES, a.steps, lib_steps)
+        rows = kernel_table(kt, lib_kt, a.clips_per_gpu * T_FRAMES, kt_steps, lib_steps)
         dom = next((r for r in rows if r["kernel"] in ("msda_bwd_enc_value", "msda_bwd_enc") and "frac" in r), None)
         if dom is not None:
             traffic = None          # HBM bytes per launch from the committed rocprofv3 --pmc passes (same shape, same kernel)
@@ -514,7 +523,8 @@ def main():
                                                           % (a.clips_per_gpu * T_FRAMES),
                                 "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": traffic,
                                 "launch_us": dom["us"], "algorithmic_bytes": dom["algorithmic_bytes"],
-                                "launches_timed": int(round(dom["launches_per_step"] * a.steps))}
+                                "launches_timed": int(round(dom["launches_per_step"] * kt_steps)),
+                                "timed_in": "the timed steps" if mode == "eager" else f"{kt_steps} extra eager steps after the timed (graph) steps"}
         if rows:
             line["kernels"] = rows[:12]
         if world == 1 and not a.no_cpu_baseline and a.backbone.startswith("resnet"):
