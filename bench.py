@@ -182,6 +182,14 @@ class GraphStep:
         n_fixed = ctypes.c_int(0)
         _lib.check(_lib.lib().ocpg_graph_replace_memsets(self.graph.raw_cuda_graph(), ctypes.byref(n_fixed)), "ocpg_graph_replace_memsets")
         self.memset_nodes_replaced = n_fixed.value
+        stats = (ctypes.c_longlong * 9)()
+        _lib.check(_lib.lib().ocpg_graph_stats(self.graph.raw_cuda_graph(), stats), "ocpg_graph_stats")
+        self.graph_stats = dict(zip(("nodes", "edges", "roots", "max_out_degree", "max_in_degree", "kernel_nodes", "memset_nodes",
+                                     "memcpy_nodes", "other_nodes"), [int(v) for v in stats]))
+        cap = 4096
+        rows = (ctypes.c_longlong * (4 * cap))()
+        n_cp = _lib.lib().ocpg_graph_memcpy_nodes(self.graph.raw_cuda_graph(), rows, cap)
+        self.memcpy_nodes = [tuple(rows[4 * i:4 * i + 4]) for i in range(max(0, min(n_cp, cap)))]     # (kind, bytes, src, dst)
         self.graph.instantiate()
         self.grads = [p.grad for p in self.params]
         assert all(g is not None for g in self.grads), "a trainable parameter received no gradient"

@@ -277,6 +277,12 @@ int ocpg_attn_smallk_bwd(const void* q, long long ldq, const void* k, long long 
  * runtime of ROCm 7.x a captured hipMemsetAsync writes a stale pattern from the second launch of the instantiated graph on
  * (csrc/graph_util.hip).  *n_replaced (may be NULL) receives the number of nodes rewritten. */
 int ocpg_graph_replace_memsets(void* hip_graph, int* n_replaced);
+/* Topology of a captured graph: out[9] = nodes, edges, roots, max out-degree, max in-degree, kernel / memset / memcpy / other node
+ * counts (a one-stream capture is a chain: roots 1, degrees <= 1). */
+int ocpg_graph_stats(void* hip_graph, long long* out9);
+/* Memcpy nodes of a captured graph: out[4 i ..] = kind (hipMemcpyKind), bytes, source, destination; returns their number (at most
+ * cap are written).  Host-to-device nodes re-read their host source on every replay. */
+int ocpg_graph_memcpy_nodes(void* hip_graph, long long* out, int cap);
 
 /* library / build identification: returns e.g. "ocpg_hip gfx950 r1" */
 const char* ocpg_hip_version(void);

@@ -34,6 +34,8 @@ SIGNATURES = {
     "ocpg_gemm": [_vp, _vp, _vp, _vp] + [_int] * 4 + [ctypes.c_longlong] * 10 + [ctypes.c_float, ctypes.c_float, _vp],
     "ocpg_gemm_plans": [],
     "ocpg_graph_replace_memsets": [_vp, _vp],
+    "ocpg_graph_stats": [_vp, _vp],
+    "ocpg_graph_memcpy_nodes": [_vp, _vp, _int],
     "ocpg_gemm_bn_act": [_vp] * 6 + [_int, _int] + [ctypes.c_longlong] * 3 + [_vp],
     "ocpg_levelset_fwd_f32": [_vp] * 3 + [_int] * 6 + [_vp] * 4,
     "ocpg_levelset_bwd_f32": [_vp] * 5 + [_int] * 6 + [_vp] * 3,

@@ -463,9 +463,14 @@ __global__ __launch_bounds__(NT) void k_scatter_col(const float* __restrict__ lo
 #ifdef EXP_NO_ACC
       nnz = 0;
 #endif
-      for (int kk = tid / G; kk < nnz; kk += GROUPS) {
-        const int pp = nz[kk];
-        const int n = cnt[pp];
+      // Two neighbouring lane groups (16 lanes) flush together so that every atomic request carries a full 64-byte line of
+      // ONE pixel (G = 8): the memory-side atomic path is request-bound, and 32-byte requests were half empty.
+      for (int kk0 = (tid / (2 * G)) * 2; kk0 < nnz; kk0 += GROUPS) {
+        const int odd = (tid / G) & 1;
+        const int kk = kk0 + odd;
+        const bool valid = kk < nnz;
+        const int pp = valid ? nz[kk] : 0;
+        const int n = valid ? cnt[pp] : 0;
         const Item* lst = items + start[pp];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         int t = 0;
@@ -484,14 +489,36 @@ __global__ __launch_bounds__(NT) void k_scatter_col(const float* __restrict__ lo
           acc.x += i0.w * g0.x; acc.y += i0.w * g0.y; acc.z += i0.w * g0.z; acc.w += i0.w * g0.w;
         }
         const int dy = (int)udiv(pp, ww, mw);
-        float* g = gvl + ((long long)(wy0 + dy) * W + wx0 + pp - dy * ww) * MD + j;     // lane j owns channels j, j+G, j+2G, j+3G:
+        const int gpix = (wy0 + dy) * W + wx0 + pp - dy * ww;                             // pixel of this group in the level
 #ifndef EXP_NO_FLUSH
-        atomicAdd(g, acc.x);                                                              // one instruction = 4*G contiguous bytes per pixel
-        atomicAdd(g + G, acc.y);
-        atomicAdd(g + 2 * G, acc.z);
-        atomicAdd(g + 3 * G, acc.w);
+        if (G == 8) {
+          // lane j of the even group holds channels j, j+8, j+16, j+24 of pixel A, the odd group the same of pixel B; after the
+          // exchange the 16 lanes write A[0..15], A[16..31], B[0..15], B[16..31]: one 64-byte request each
+          const float send1 = odd ? acc.x : acc.y, send2 = odd ? acc.z : acc.w;
+          const float got1 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send1), 0x128, 0xF, 0xF, true));   // row_ror:8 = lane ^ 8
+          const float got2 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send2), 0x128, 0xF, 0xF, true));
+          const int opix = __builtin_amdgcn_mov_dpp(valid ? gpix : -1, 0x128, 0xF, 0xF, true);
+          const int pixA = odd ? opix : (valid ? gpix : -1), pixB = odd ? (valid ? gpix : -1) : opix;
+          const int jj = j + (odd ? G : 0);
+          if (pixA >= 0) {
+            float* g = gvl + (long long)pixA * MD + jj;
+            atomicAdd(g, odd ? got1 : acc.x);
+            atomicAdd(g + 2 * G, odd ? got2 : acc.z);
+          }
+          if (pixB >= 0) {
+            float* g = gvl + (long long)pixB * MD + jj;
+            atomicAdd(g, odd ? acc.y : got1);
+            atomicAdd(g + 2 * G, odd ? acc.w : got2);
+          }
+        } else if (valid) {
+          float* g = gvl + (long long)gpix * MD + j;      // lane j owns channels j, j+G, j+2G, j+3G: 4*G contiguous bytes per instruction
+          atomicAdd(g, acc.x);
+          atomicAdd(g + G, acc.y);
+          atomicAdd(g + 2 * G, acc.z);
+          atomicAdd(g + 3 * G, acc.w);
+        }
 #endif
-        if (j == 0) cnt[pp] = 0;        // ready for the next level
+        if (valid && j == 0) cnt[pp] = 0;        // ready for the next level
       }
       STAMP(5);
       lds_barrier();
