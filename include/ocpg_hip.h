@@ -272,6 +272,14 @@ int ocpg_attn_smallk_bwd(const void* q, long long ldq, const void* k, long long 
                          int B, int H, int hd, int Lk, float pdrop, unsigned long long seed, unsigned long long offset, void* dq,
                          long long lddq, float* dk, float* dv, int dtype, void* stream);
 
+/* LFM coefficient branch (models/modules.py:17-19,36-39: `self.fc(self.pool(self.laplace(x)))` with laplace a 3x3 VALID conv): the
+ * spatial mean of a convolution is linear in the input, mean conv(x)[co] = b[co] + sum w[co,ci,ky,kx] m[ci,ky,kx] with m the mean
+ * of x[ci] over the (h-2)x(w-2) window at offset (ky,kx).  x [planes, h, w] fp32 contiguous -> out [planes, 9] window means
+ * (as_bf16 != 0: every element is rounded to bf16 first, as the autocast convolution would see it); bwd: gm [planes, 9] ->
+ * dx [planes, h, w] fully written. */
+int ocpg_window_means3x3_fwd(const float* x, long long planes, int h, int w, int as_bf16, float* out, void* stream);
+int ocpg_window_means3x3_bwd(const float* gm, long long planes, int h, int w, float* dx, void* stream);
+
 /* Whole-step HIP-graph capture support (no reference counterpart: the reference launches eagerly).  Replaces every memset node of
  * a captured, not yet instantiated hipGraph_t by a kernel node with the same destination, value, extent and edges: with the HIP
  * runtime of ROCm 7.x a captured hipMemsetAsync writes a stale pattern from the second launch of the instantiated graph on

@@ -33,6 +33,8 @@ SIGNATURES = {
     "ocpg_conv3x3_mfma_dgrad": [_vp, _vp] + [_int] * 6 + [_vp, _vp],
     "ocpg_gemm": [_vp, _vp, _vp, _vp] + [_int] * 4 + [ctypes.c_longlong] * 10 + [ctypes.c_float, ctypes.c_float, _vp],
     "ocpg_gemm_plans": [],
+    "ocpg_window_means3x3_fwd": [_vp, ctypes.c_longlong, _int, _int, _int, _vp, _vp],
+    "ocpg_window_means3x3_bwd": [_vp, ctypes.c_longlong, _int, _int, _vp, _vp],
     "ocpg_graph_replace_memsets": [_vp, _vp],
     "ocpg_graph_stats": [_vp, _vp],
     "ocpg_graph_memcpy_nodes": [_vp, _vp, _int],

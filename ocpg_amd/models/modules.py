@@ -11,9 +11,10 @@ from torch import nn
 
 from ..util.misc import memo
 from . import amp_cache
-from .ops.functions.spectral_func import spectral_gate
+from .ops.functions.spectral_func import conv3x3_valid_spatial_mean, spectral_gate
 
 FUSED_GATE = True       # A/B switch: fused spectral gate kernel
+LAPLACE_MEAN = True     # A/B switch: mean(laplace(x)) as nine window means + one small matrix product (no convolution)
 
 
 class LFMResizeAdaptive(nn.Module):
@@ -39,7 +40,19 @@ class LFMResizeAdaptive(nn.Module):
         # are cast back with `.float()` (modules.py:56).  Without autocast everything is fp32.
         b, c, h, w = x.shape
         x = x.float()
-        coef = self.fc(self.laplace(x).mean(dim=(2, 3))).view(b, 1, 1, 1)
+        if x.is_cuda and LAPLACE_MEAN and self.laplace.kernel_size == (3, 3) and self.laplace.padding == (0, 0):
+            # the spatial mean of a convolution is linear in its input (csrc/lfm.hip): same products, no 3x3 convolution
+            amp = torch.is_autocast_enabled("cuda")
+            wl, bl = amp_cache.lookup(self.laplace.weight), amp_cache.lookup(self.laplace.bias)
+            if amp:
+                dt = torch.get_autocast_dtype("cuda")
+                wl, bl = wl.to(dt), bl.to(dt)
+            lap_mean = conv3x3_valid_spatial_mean(x, wl, bl, amp and wl.dtype == torch.bfloat16)
+            if amp:
+                lap_mean = lap_mean.to(wl.dtype)          # the dtype the autocast convolution + mean would have produced
+        else:
+            lap_mean = self.laplace(x).mean(dim=(2, 3))
+        coef = self.fc(lap_mean).view(b, 1, 1, 1)
         # the Gaussian of level 0 and its chain of bilinear resizes depend only on the map sizes: memoised (util.misc.memo)
         if gauss_map is None:
             key = ("gauss", h // 2, w // 2, h, w, float(self.sigma))

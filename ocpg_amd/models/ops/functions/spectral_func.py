@@ -34,3 +34,35 @@ class SpectralGate(Function):
 
 def spectral_gate(spec, coef, high):
     return SpectralGate.apply(spec, coef, high)
+
+
+class WindowMeans3x3(Function):
+    """x [N,C,h,w] fp32 -> [N, C*9]: mean of every plane over the nine (h-2)x(w-2) windows at offsets (ky,kx) (csrc/lfm.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, as_bf16):
+        x = x.contiguous()
+        n, c, h, w = x.shape
+        out = torch.empty((n, c * 9), dtype=torch.float32, device=x.device)
+        check(lib().ocpg_window_means3x3_fwd(x.data_ptr(), n * c, h, w, int(as_bf16), out.data_ptr(), torch.cuda.current_stream().cuda_stream),
+              "ocpg_window_means3x3_fwd")
+        ctx.shape = (n, c, h, w)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gm):
+        n, c, h, w = ctx.shape
+        gm = gm.float().contiguous()
+        dx = torch.empty((n, c, h, w), dtype=torch.float32, device=gm.device)
+        check(lib().ocpg_window_means3x3_bwd(gm.data_ptr(), n * c, h, w, dx.data_ptr(), torch.cuda.current_stream().cuda_stream),
+              "ocpg_window_means3x3_bwd")
+        return dx, None
+
+
+def conv3x3_valid_spatial_mean(x, weight, bias, as_bf16):
+    """== F.conv2d(x, weight, bias).mean(dim=(2, 3)) for a 3x3 valid convolution, without the convolution.  `weight` is the copy
+    the convolution would have used (bf16 under autocast): the products are the same, only the summation order differs."""
+    m = WindowMeans3x3.apply(x, as_bf16)
+    with torch.autocast(device_type=x.device.type, enabled=False):
+        return torch.nn.functional.linear(m, weight.float().flatten(1), None if bias is None else bias.float())

@@ -257,6 +257,52 @@ def test_lfm_fused_spectral_gate(dev):
         assert (u - v).abs().max().item() <= 2e-5 * v.abs().max().item() + 1e-7, ((u - v).abs().max().item(), v.abs().max().item())
 
 
+@pytest.mark.parametrize("amp", [None, torch.bfloat16])
+def test_lfm_laplace_mean_without_convolution(dev, amp):
+    """LFM coefficient branch: nine window means + one small matrix product (csrc/lfm.hip) == conv3x3(valid) followed by the
+    spatial mean (reference models/modules.py:36-39): block output, input gradient and every parameter gradient; the raw
+    identity is also checked on odd sizes including the 3x3 map (a single output position)."""
+    from ocpg_amd.models import modules
+    from ocpg_amd.models.ops.functions.spectral_func import conv3x3_valid_spatial_mean
+    torch.manual_seed(0)
+    for (n, c, h, w) in ((2, 5, 3, 3), (3, 7, 4, 9), (2, 16, 23, 37)):
+        x = torch.randn(n, c, h, w, device=dev, requires_grad=True)
+        wt = torch.randn(6, c, 3, 3, device=dev, requires_grad=True)
+        bs = torch.randn(6, device=dev, requires_grad=True)
+        want = torch.nn.functional.conv2d(x, wt, bs).mean(dim=(2, 3))
+        got = conv3x3_valid_spatial_mean(x, wt, bs, False)
+        assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item() + 1e-6
+        go = torch.randn_like(want)
+        for a, b_ in zip(torch.autograd.grad((got * go).sum(), (x, wt, bs)), torch.autograd.grad((want * go).sum(), (x, wt, bs))):
+            assert (a - b_).abs().max().item() <= 2e-5 * b_.abs().max().item() + 1e-6
+    lfm = modules.LFMResizeAdaptive(32, 7).to(dev)
+    x1 = torch.randn(3, 32, 23, 37, device=dev)
+    x2 = torch.randn(3, 32, 12, 19, device=dev)
+    def run(on, dtype):
+        modules.LAPLACE_MEAN = on
+        try:
+            a, b_ = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+            lfm.zero_grad()
+            with torch.autocast("cuda", dtype=dtype, enabled=dtype is not None):
+                y1, g = lfm(a)
+                y2, _ = lfm(b_, g)
+            (y1.float().square().mean() + y2.float().square().mean()).backward()
+            return [y1.detach().float(), y2.detach().float(), a.grad, b_.grad] + [p.grad.clone() for p in lfm.parameters()]
+        finally:
+            modules.LAPLACE_MEAN = True
+    if amp is None:
+        for u, v in zip(run(True, None), run(False, None)):
+            assert (u - v).abs().max().item() <= 2e-5 * v.abs().max().item() + 1e-7, ((u - v).abs().max().item(), v.abs().max().item())
+    else:
+        # bf16: the convolution rounds every one of its outputs (and output gradients) to bf16 before the mean, the window form
+        # does not: judged against the fp32 block, the window form must be at least as close as the convolution form
+        ref, conv, mine = run(False, None), run(False, amp), run(True, amp)
+        for r, cv, mn in zip(ref, conv, mine):
+            scale = r.abs().max().item()
+            assert (mn - r).abs().max().item() <= 1.5 * (cv - r).abs().max().item() + 1e-2 * scale + 1e-7, \
+                ((mn - r).abs().max().item(), (cv - r).abs().max().item(), scale)
+
+
 @pytest.mark.parametrize("num_classes", [1, 7])
 def test_hip_det_losses_equal_torch_formulas(dev, num_classes):
     """csrc/det_loss.hip (focal classification + L1 + GIoU, all layers per launch, GIoU gradient by forward-mode duals)
