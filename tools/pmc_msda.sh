@@ -3,7 +3,7 @@
 # micro-benchmark at N=10 frames (= bench.py: 2 clips x 5 frames, encoder shape, the model's ring-offset sampling pattern);
 # writes gpurun_out/pmc_{f,w,a}.csv (counter_collection rows of the MSDA kernels) and gpurun_out/msda_pmc.json
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-export MSDA_FRAMES=10
+export MSDA_FRAMES=10 MSDA_MODES=ring MSDA_COLS=1
 for spec in "f FETCH_SIZE" "w WRITE_SIZE" "a TCC_EA0_ATOMIC_sum"; do
   set -- $spec
   rm -rf /tmp/pmc_$1
