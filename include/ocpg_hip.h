@@ -244,6 +244,13 @@ int ocpg_det_loss_bwd_f32(const float* logits, const float* boxes, const long lo
  * spectrum X [N,C,h,w] (interleaved re/im), coef [N], high [h*w]; bwd: dX complex [N,C,h,w] fully written, part
  * [N, C * ceil(hw/256)] partial sums with dcoef[n] = sum(part[n]). */
 int ocpg_spectral_gate_fwd(const void* X, const float* coef, const float* high, int N, int C, int hw, float* out, void* stream);
+/* Channels-last forms of the same block (round 2): the [Re || Im] side as [N, hw, 2C] in the 1x1 convs' compute dtype (0 fp32 /
+ * 1 bf16 / 2 fp16), the complex side as [N, C, hw]; 64 x 64 tile transposes through LDS.  c2p = the gate forward (coef, high)
+ * or the plain split (coef NULL: the backward of torch.complex(yr, yi), models/modules.py:52-53); p2c = the gate backward
+ * (Xs = the saved spectrum: dcoef partials into part [N, ceil(C/64) * ceil(hw/64)]) or the plain merge (Xs, coef NULL). */
+int ocpg_spectral_c2p(const void* X, const float* coef, const float* high, int N, int C, int hw, void* pair, int dtype, void* stream);
+int ocpg_spectral_p2c(const void* pair, const void* Xs, const float* coef, const float* high, int N, int C, int hw, void* out, float* part,
+                      int dtype, void* stream);
 int ocpg_spectral_gate_bwd(const float* gout, const void* X, const float* coef, const float* high, int N, int C, int hw, void* dX, float* part,
                            void* stream);
 

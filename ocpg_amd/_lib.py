@@ -56,6 +56,8 @@ SIGNATURES = {
     "ocpg_det_loss_bwd_f32": [_vp] * 8 + [ctypes.c_float] + [_int] * 5 + [_vp] * 3,
     "ocpg_spectral_gate_fwd": [_vp] * 3 + [_int] * 3 + [_vp, _vp],
     "ocpg_spectral_gate_bwd": [_vp] * 4 + [_int] * 3 + [_vp, _vp, _vp],
+    "ocpg_spectral_c2p": [_vp] * 3 + [_int] * 3 + [_vp, _int, _vp],
+    "ocpg_spectral_p2c": [_vp] * 4 + [_int] * 3 + [_vp, _vp, _int, _vp],
     "ocpg_masked_ce_fwd_f32": [_vp] * 3 + [_int, ctypes.c_longlong, _vp, _vp],
     "ocpg_masked_ce_bwd_f32": [_vp] * 4 + [_int, ctypes.c_longlong, _vp, _vp],
     "ocpg_im2col3x3_nhwc": [_vp] + [_int] * 6 + [_vp, _int, _vp],

@@ -11,9 +11,10 @@ from torch import nn
 
 from ..util.misc import memo
 from . import amp_cache
-from .ops.functions.spectral_func import conv3x3_valid_spatial_mean, spectral_gate
+from .ops.functions.spectral_func import conv3x3_valid_spatial_mean, pair_to_complex, spectral_gate, spectral_gate_cl
 
 FUSED_GATE = True       # A/B switch: fused spectral gate kernel
+GATE_NHWC = True        # A/B switch: gate output / inverse-FFT input in channels-last memory (1x1 convs as GEMMs, no casts / layout copies)
 LAPLACE_MEAN = True     # A/B switch: mean(laplace(x)) as nine window means + one small matrix product (no convolution)
 
 
@@ -63,6 +64,12 @@ class LFMResizeAdaptive(nn.Module):
             high = memo("lfm_gauss", key, x.device, lambda: F.interpolate(gauss_map, size=(h, w), mode="bilinear", align_corners=False))
         if key is not None:
             high._ocpg_key = key
+        if x.is_cuda and FUSED_GATE and GATE_NHWC and c % 4 == 0:
+            dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
+            z = spectral_gate_cl(torch.fft.fft2(x), coef.float().reshape(b), high.reshape(h, w), dt)
+            y = self.conv2(F.relu(self.conv1(z)))                   # channels-last in, channels-last out: two GEMMs
+            y = torch.fft.ifft2(pair_to_complex(y), s=(h, w)).real.float()
+            return x + y, high
         if x.is_cuda and FUSED_GATE:
             # gate, real/imag split and concatenation in one pass (csrc/spectral.hip)
             z = spectral_gate(torch.fft.fft2(x), coef.float().reshape(b), high.reshape(h, w))

@@ -66,3 +66,74 @@ def conv3x3_valid_spatial_mean(x, weight, bias, as_bf16):
     m = WindowMeans3x3.apply(x, as_bf16)
     with torch.autocast(device_type=x.device.type, enabled=False):
         return torch.nn.functional.linear(m, weight.float().flatten(1), None if bias is None else bias.float())
+
+
+_DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+
+class SpectralGateCL(Function):
+    """The gate with its [Re || Im] side in CHANNELS-LAST memory and the 1x1 convs' compute dtype (csrc/spectral.hip c2p / p2c):
+    the result is a [N, 2C, h, w] tensor whose memory is [N, h, w, 2C], so the following 1x1 convs are plain GEMMs on it and no
+    cast / layout copy sits between the FFT and the GEMM."""
+
+    @staticmethod
+    def forward(ctx, spec, coef, high, dtype):
+        spec = spec.contiguous()
+        coef, high = coef.float().contiguous(), high.float().contiguous()
+        n, c, h, w = spec.shape
+        pair = torch.empty((n, h, w, 2 * c), dtype=dtype, device=spec.device)
+        check(lib().ocpg_spectral_c2p(torch.view_as_real(spec).data_ptr(), coef.data_ptr(), high.data_ptr(), n, c, h * w, pair.data_ptr(),
+                                      _DT[dtype], torch.cuda.current_stream().cuda_stream), "ocpg_spectral_c2p")
+        ctx.save_for_backward(spec, coef, high)
+        return pair.permute(0, 3, 1, 2)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gz):
+        spec, coef, high = ctx.saved_tensors
+        n, c, h, w = spec.shape
+        g = gz.permute(0, 2, 3, 1).contiguous()
+        if g.dtype not in _DT:
+            g = g.float()
+        dx = torch.empty((n, c, h, w, 2), dtype=torch.float32, device=spec.device)
+        nb = ((c + 63) // 64) * ((h * w + 63) // 64)
+        part = torch.empty((n, nb), dtype=torch.float32, device=spec.device)
+        check(lib().ocpg_spectral_p2c(g.data_ptr(), torch.view_as_real(spec).data_ptr(), coef.data_ptr(), high.data_ptr(), n, c, h * w,
+                                      dx.data_ptr(), part.data_ptr(), _DT[g.dtype], torch.cuda.current_stream().cuda_stream), "ocpg_spectral_p2c")
+        return torch.view_as_complex(dx), part.sum(1), None, None
+
+
+class PairToComplex(Function):
+    """y [N, 2C, h, w] in channels-last memory (any of fp32 / bf16 / fp16) -> complex64 [N, C, h, w] = y[:, :C] + i y[:, C:]
+    (`torch.complex(*torch.chunk(y.float(), 2, dim=1))`, models/modules.py:52-53) in one transposing pass each way."""
+
+    @staticmethod
+    def forward(ctx, y):
+        n, c2, h, w = y.shape
+        src = y.permute(0, 2, 3, 1).contiguous()
+        if src.dtype not in _DT:
+            src = src.float()
+        out = torch.empty((n, c2 // 2, h, w, 2), dtype=torch.float32, device=y.device)
+        check(lib().ocpg_spectral_p2c(src.data_ptr(), None, None, None, n, c2 // 2, h * w, out.data_ptr(), None, _DT[src.dtype],
+                                      torch.cuda.current_stream().cuda_stream), "ocpg_spectral_p2c")
+        ctx.dtype = y.dtype
+        return torch.view_as_complex(out)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gc):
+        gc = gc.contiguous()
+        n, c, h, w = gc.shape
+        dt = ctx.dtype if ctx.dtype in _DT else torch.float32
+        pair = torch.empty((n, h, w, 2 * c), dtype=dt, device=gc.device)
+        check(lib().ocpg_spectral_c2p(torch.view_as_real(gc).data_ptr(), None, None, n, c, h * w, pair.data_ptr(), _DT[dt],
+                                      torch.cuda.current_stream().cuda_stream), "ocpg_spectral_c2p")
+        return pair.permute(0, 3, 1, 2).to(ctx.dtype)
+
+
+def spectral_gate_cl(spec, coef, high, dtype):
+    return SpectralGateCL.apply(spec, coef, high, dtype)
+
+
+def pair_to_complex(y):
+    return PairToComplex.apply(y)

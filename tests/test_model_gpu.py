@@ -258,6 +258,63 @@ def test_lfm_fused_spectral_gate(dev):
 
 
 @pytest.mark.parametrize("amp", [None, torch.bfloat16])
+def test_lfm_channels_last_gate(dev, amp):
+    """LFM with the gate output / inverse-FFT input in channels-last memory (csrc/spectral.hip c2p / p2c, 1x1 convs as GEMMs)
+    == the NCHW formulation: output, input gradient, every parameter gradient; ragged sizes (channels and pixels not multiples of
+    the 64 x 64 tile); plus the raw kernels against tensor ops."""
+    from ocpg_amd.models import modules
+    from ocpg_amd.models.ops.functions import spectral_func as sf
+    torch.manual_seed(0)
+    # raw kernels
+    n, c, h, w = 2, 36, 5, 13
+    spec = torch.complex(torch.randn(n, c, h, w, device=dev), torch.randn(n, c, h, w, device=dev)).requires_grad_(True)
+    coef = torch.rand(n, device=dev).requires_grad_(True)
+    high = torch.rand(h, w, device=dev)
+    z = sf.spectral_gate_cl(spec, coef, high, torch.float32)
+    assert z.shape == (n, 2 * c, h, w) and z.is_contiguous(memory_format=torch.channels_last)
+    want = spec * (1 - coef.view(n, 1, 1, 1) * high)
+    want = torch.cat([want.real, want.imag], 1)
+    assert (z - want).abs().max().item() <= 1e-6
+    go = torch.randn_like(want)
+    for a, b_ in zip(torch.autograd.grad((z * go).sum(), (spec, coef)), torch.autograd.grad((want * go).sum(), (spec, coef))):
+        assert (a - b_).abs().max().item() <= 2e-5 * b_.abs().max().item() + 1e-6
+    y = torch.randn(n, 2 * c, h, w, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    cplx = sf.pair_to_complex(y)
+    want_c = torch.complex(*torch.chunk(y, 2, dim=1))
+    assert torch.equal(torch.view_as_real(cplx), torch.view_as_real(want_c))
+    gc = torch.complex(torch.randn(n, c, h, w, device=dev), torch.randn(n, c, h, w, device=dev))
+    ga, = torch.autograd.grad(torch.view_as_real(cplx * gc.conj()).select(-1, 0).sum(), y)
+    gb, = torch.autograd.grad(torch.view_as_real(want_c * gc.conj()).select(-1, 0).sum(), y)
+    assert (ga - gb).abs().max().item() <= 1e-6
+    # the block
+    lfm = modules.LFMResizeAdaptive(36, 7).to(dev)
+    x1 = torch.randn(3, 36, 23, 37, device=dev)
+    x2 = torch.randn(3, 36, 12, 19, device=dev)
+
+    def run(on, dtype):
+        modules.GATE_NHWC = on
+        try:
+            a, b_ = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+            lfm.zero_grad()
+            with torch.autocast("cuda", dtype=dtype, enabled=dtype is not None):
+                y1, g = lfm(a)
+                y2, _ = lfm(b_, g)
+            (y1.float().square().mean() + y2.float().square().mean()).backward()
+            return [y1.detach().float(), y2.detach().float(), a.grad, b_.grad] + [p.grad.clone() for p in lfm.parameters()]
+        finally:
+            modules.GATE_NHWC = True
+    if amp is None:
+        for u, v in zip(run(True, None), run(False, None)):
+            assert (u - v).abs().max().item() <= 3e-5 * v.abs().max().item() + 1e-7, ((u - v).abs().max().item(), v.abs().max().item())
+    else:
+        ref, nchw, cl = run(False, None), run(False, amp), run(True, amp)
+        for r, a, b_ in zip(ref, nchw, cl):
+            scale = r.abs().max().item()
+            assert (b_ - r).abs().max().item() <= 1.5 * (a - r).abs().max().item() + 1e-2 * scale + 1e-7, \
+                ((b_ - r).abs().max().item(), (a - r).abs().max().item(), scale)
+
+
+@pytest.mark.parametrize("amp", [None, torch.bfloat16])
 def test_lfm_laplace_mean_without_convolution(dev, amp):
     """LFM coefficient branch: nine window means + one small matrix product (csrc/lfm.hip) == conv3x3(valid) followed by the
     spatial mean (reference models/modules.py:36-39): block output, input gradient and every parameter gradient; the raw
