@@ -11,8 +11,12 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ...amp_cache import TokenLinear
+from ...amp_cache import TokenLinear, linear
+from ....util.misc import memo
 from ..functions import MSDeformAttnFunction
+
+
+MERGED_QUERY_PROJ = True      # A/B switch: sampling_offsets and attention_weights as ONE GEMM over the query (they share their input)
 
 
 def _is_power_of_2(n):
@@ -68,11 +72,33 @@ class MSDeformAttn(nn.Module):
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], 0.0)
         value = value.view(N, S, M, self.d_model // M)
-        offsets = self.sampling_offsets(query).view(N, Lq, M, L, P, 2)
-        weights = F.softmax(self.attention_weights(query).view(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
+        if MERGED_QUERY_PROJ and query.is_cuda:
+            # One GEMM for both query projections (same input, [256 + 128] output columns): one forward GEMM, one input-gradient
+            # GEMM and one weight-gradient GEMM instead of two each plus the add of the two input gradients.  With 2-d reference
+            # points and host-known level shapes the division of the offsets by (W_l, H_l) is folded into the (tiny) weight:
+            # x (W s)^T + b s == (x W^T + b) s column by column -- same products, the scaling moves from 52 MB of offsets to 256 rows.
+            n_off = M * L * P * 2
+            so_w, so_b = self.sampling_offsets.weight, self.sampling_offsets.bias
+            folded = reference_points.shape[-1] == 2 and host is not None
+            if folded:
+                key = ("msda_inv_wh", tuple(host.flatten().tolist()), M, P)
+                inv = memo("msda", key, query.device, lambda: (1.0 / torch.stack([host[:, 1], host[:, 0]], -1).float())[None, :, None, :]
+                           .expand(M, L, P, 2).reshape(-1).to(query.device))
+                so_w, so_b = so_w * inv[:, None], so_b * inv
+            both = linear(query, torch.cat([so_w, self.attention_weights.weight], 0), torch.cat([so_b, self.attention_weights.bias], 0))
+            off2, logit2 = torch.split(both, [n_off, M * L * P], dim=-1)      # split: its backward is ONE cat (two slices: 2 x (zeros + copy) + add)
+            offsets = off2.view(N, Lq, M, L, P, 2)
+            weights = F.softmax(logit2.view(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
+        else:
+            folded = False
+            offsets = self.sampling_offsets(query).view(N, Lq, M, L, P, 2)
+            weights = F.softmax(self.attention_weights(query).view(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
         if reference_points.shape[-1] == 2:
-            wh = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
-            loc = reference_points[:, :, None, :, None, :] + offsets / wh[None, None, None, :, None, :]
+            if folded:
+                loc = reference_points[:, :, None, :, None, :] + offsets
+            else:
+                wh = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
+                loc = reference_points[:, :, None, :, None, :] + offsets / wh[None, None, None, :, None, :]
         elif reference_points.shape[-1] == 4:
             loc = reference_points[:, :, None, :, None, :2] + offsets / P * reference_points[:, :, None, :, None, 2:] * 0.5
         else:
