@@ -157,6 +157,7 @@ class DeformableTransformerDecoder(nn.Module):
                 query_pos=None, src_padding_mask=None):
         out = tgt
         inter, inter_refs, inter_samples = [], [], []
+        self.box_deltas = [] if self.bbox_embed is not None else None      # handed to the caller's box head (same module, same input)
         samples_keep = None
         for lid, layer in enumerate(self.layers):
             if reference_points.shape[-1] == 4:
@@ -173,10 +174,11 @@ class DeformableTransformerDecoder(nn.Module):
 
             if self.bbox_embed is not None:
                 delta = self.bbox_embed[lid](out)
+                self.box_deltas.append(delta)
                 if reference_points.shape[-1] == 4:
                     new_ref = (delta + inverse_sigmoid(reference_points)).sigmoid()
                 else:
-                    new_ref = torch.cat([delta[..., :2] + inverse_sigmoid(reference_points), delta[..., 2:]], -1).sigmoid()
+                    new_ref = (delta + F.pad(inverse_sigmoid(reference_points), (0, 2))).sigmoid()
                 reference_points = new_ref.detach()
             if self.return_intermediate:
                 inter.append(out)
@@ -264,11 +266,15 @@ class DeformableTransformer(nn.Module):
         reference_points = self.reference_points(query_pos).sigmoid()
         hs, inter_refs, inter_samples = self.decoder(tgt, reference_points, memory, spatial_shapes, level_start_index,
                                                      valid_ratios, query_pos, mask)
+        # with iterative box refinement the decoder has already evaluated bbox_embed[l](hs[l]) (only a detached copy is used for the
+        # next layer's reference points): the model's box head re-uses these instead of running the same three GEMMs again.
+        # Consumed here so that no autograd graph stays referenced from the module between steps.
+        box_deltas, self.decoder.box_deltas = (self.decoder.box_deltas if self.decoder.return_intermediate else None), None
         feats, start = [], 0
         for (h, w) in shapes_host[: self.num_feature_level - 1]:
             feats.append(memory[:, start:start + h * w].reshape(b * t, h, w, c).permute(0, 3, 1, 2).contiguous())
             start += h * w
-        return hs, feats, reference_points, inter_refs, None, None, inter_samples
+        return hs, feats, reference_points, inter_refs, box_deltas, None, inter_samples
 
 
 def build_deforamble_transformer(args):

@@ -242,22 +242,24 @@ class OCPG(nn.Module):
 
         # ---- deformable transformer ----
         text_embed = text_sentence[:, None, None, :].expand(-1, t, self.num_queries, -1)
-        hs, memory, init_reference, inter_references, _, _, inter_samples = \
+        hs, memory, init_reference, inter_references, box_deltas, _, inter_samples = \
             self.transformer(srcs, text_embed, masks, poses, self.query_embed.weight)
         nl = hs.shape[0]
 
         # ---- class / box heads ----
         out = {}
         classes, coords = [], []
+        hs_l = hs.unbind(0)              # one StackBackward instead of a zeros + copy + add per level
+        refs_l = (init_reference,) + tuple(inter_references.unbind(0)[:-1])
         for lvl in range(nl):
-            ref = inverse_sigmoid(init_reference if lvl == 0 else inter_references[lvl - 1])
-            delta = self.bbox_embed[lvl](hs[lvl])
+            ref = inverse_sigmoid(refs_l[lvl])
+            delta = box_deltas[lvl] if box_deltas is not None else self.bbox_embed[lvl](hs_l[lvl])
             if ref.shape[-1] == 4:
                 delta = delta + ref
             else:
                 assert ref.shape[-1] == 2
-                delta = torch.cat([delta[..., :2] + ref, delta[..., 2:]], -1)
-            classes.append(self.class_embed[lvl](hs[lvl]))
+                delta = delta + F.pad(ref, (0, 2))          # == cat([delta[..., :2] + ref, delta[..., 2:]]): no slice backward (zeros + copy + add)
+            classes.append(self.class_embed[lvl](hs_l[lvl]))
             coords.append(delta.sigmoid())
         outputs_class = torch.stack(classes).unflatten(1, (b, t))                 # [l, b, t, q, k]
         outputs_coord = torch.stack(coords).unflatten(1, (b, t))                  # [l, b, t, q, 4]
