@@ -150,6 +150,10 @@ class DeformableTransformerDecoder(nn.Module):
         self.layers = _clones(decoder_layer, num_layers)
         self.num_layers = num_layers
         self.return_intermediate = return_intermediate
+        # the top-k sampling locations of every layer (deformable_transformer.py:368-375,393): returned by the reference's
+        # transformer and never read by its model (models/ocpg.py:300 is the only consumer and drops them) -- OCPG switches the
+        # computation (div + topk + gather per layer) off; the decoder on its own keeps the reference's behaviour
+        self.compute_samples = True
         self.bbox_embed = None      # set by OCPG for iterative box refinement
         self.class_embed = None
 
@@ -167,10 +171,11 @@ class DeformableTransformerDecoder(nn.Module):
                 ref_in = reference_points[:, :, None] * src_valid_ratios[:, None]
             out, loc, weights = layer(out, query_pos, ref_in, src, src_spatial_shapes, src_level_start_index, src_padding_mask)
 
-            n, lq = loc.shape[:2]
-            loc = loc / src_valid_ratios[:, None, None, :, None, :]
-            top_idx = weights.reshape(n, lq, -1).topk(self.TOPK_SAMPLES, dim=2)[1]
-            samples_keep = torch.gather(loc.reshape(n, lq, -1, 2), 2, top_idx.unsqueeze(-1).expand(-1, -1, -1, 2))
+            if self.compute_samples:
+                n, lq = loc.shape[:2]
+                loc = loc / src_valid_ratios[:, None, None, :, None, :]
+                top_idx = weights.reshape(n, lq, -1).topk(self.TOPK_SAMPLES, dim=2)[1]
+                samples_keep = torch.gather(loc.reshape(n, lq, -1, 2), 2, top_idx.unsqueeze(-1).expand(-1, -1, -1, 2))
 
             if self.bbox_embed is not None:
                 delta = self.bbox_embed[lid](out)
@@ -183,9 +188,10 @@ class DeformableTransformerDecoder(nn.Module):
             if self.return_intermediate:
                 inter.append(out)
                 inter_refs.append(reference_points)
-                inter_samples.append(samples_keep)
+                if self.compute_samples:
+                    inter_samples.append(samples_keep)
         if self.return_intermediate:
-            return torch.stack(inter), torch.stack(inter_refs), torch.stack(inter_samples)
+            return torch.stack(inter), torch.stack(inter_refs), (torch.stack(inter_samples) if self.compute_samples else None)
         return out, reference_points, samples_keep
 
 

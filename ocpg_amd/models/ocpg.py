@@ -141,6 +141,7 @@ class OCPG(nn.Module):
         self.rel_coord = rel_coord
         self.init_aux_head()
         self.build_controller()
+        self.transformer.decoder.compute_samples = False      # dead output in the reference's model (never read): not computed
 
     # ------------------------------------------------------------------------------------------------------
     def init_aux_head(self):
@@ -304,20 +305,20 @@ class OCPG(nn.Module):
                 # the matched query of every layer: one gather over [l, b, t, q, ...]
                 seg = m_all.permute(2, 0, 1, 3, 4, 5, 6)                            # [l, b, t, q, 16, h, w] (view)
                 gi = src_all[:, :, None, None, None, None, None].expand(nl, b, t, 1, 16, tar[0], tar[1])
-                picked = torch.gather(seg, 3, gi)[:, :, :, 0].flatten(1, 2)         # [l, (b t), 16, h, w]
+                picked = torch.gather(seg, 3, gi).squeeze(3).flatten(1, 2)          # [l, (b t), 16, h, w]
                 refined = self.mask_refine.forward_multi(list(picked.unbind(0)), features[:2], stacked=True)   # [l*(b t), 1, 2h, 2w]
                 refined = F.interpolate(refined, scale_factor=4).squeeze(1)
                 refined = refined.view(nl, b, t, *refined.shape[-2:])
                 gl = src_all[:, :, None, None, None, None].expand(nl, b, t, 1, 4 * tar[0], 4 * tar[1])
-                low = torch.gather(shuffled, 3, gl)[:, :, :, 0]                     # [l, b, t, 4h, 4w]
+                low = torch.gather(shuffled, 3, gl).squeeze(3)                      # [l, b, t, 4h, 4w]
                 out["pred_masks"] = refined[-1]
                 out["ls_features"] = ls_features
                 out["frames"] = img
                 out["pred_masks_low"] = low[-1]
                 out["aux_outputs"] = self._set_aux_loss_comprehensive(outputs_class, outputs_coord, refined, low, ls_features, img)
                 # layer-stacked views for the criterion, in ITS call order (main, aux 0, aux 1, ...): no re-stacking copies
-                def main_first(x):      # (slices + cat: no host-built index tensor, so the step stays graph-capturable)
-                    return torch.cat([x[nl - 1:], x[:nl - 1]], dim=0)
+                def main_first(x):      # rotate the last layer to the front: one kernel each way (slices + cat: 2 x (zeros + copy) + add backward)
+                    return torch.roll(x, 1, 0)
                 out["_stacked"] = {"pred_logits": main_first(outputs_class), "pred_boxes": main_first(outputs_coord),
                                    "pred_masks": main_first(refined), "pred_masks_low": main_first(low)}
         elif self.args.dataset_file not in ("a2d", "jhmdb") and "refcoco" not in self.args.dataset_file:
