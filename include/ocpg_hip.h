@@ -105,6 +105,13 @@ int ocpg_win_attn_bwd(const void* qkv, const float* bias, const float* biasT, co
                       int N, int H, int head_dim, const void* out, const void* dout, const float* lse, void* dqkv, float* Dbuf,
                       float* dbiasT, int dtype, void* stream);
 
+/* Matrix-core backward for bf16 / fp16 storage (csrc/win_attn_mfma.hip; the forward switches by itself): as ocpg_win_attn_bwd, but
+ * the bias gradient leaves as dS [BW, H, N, N] (storage dtype, (key, query) order, fully written; NULL: not needed) for the caller to
+ * sum over BW -- 2 x 232 MB of streaming traffic at Swin-T stage 1 instead of 464 MB of float atomics.  -2000: shape not served. */
+int ocpg_win_attn_bwd_mfma(const void* qkv, const float* bias, const float* biasT, const int* region, float scale, int BW, int NW, int N,
+                           int H, int head_dim, const void* out, const void* dout, const float* lse, void* dqkv, float* Dbuf, void* dS,
+                           int dtype, void* stream);
+
 /* Dynamic (per-query) mask head, forward -- replaces OCPG.dynamic_mask_with_coords + mask_heads_forward
  * (models/ocpg.py:475-549) for the reference's fixed head shape (2 layers, 16 channels, relative coordinates on).
  * Q counts the parameter sets per frame: the reference calls the head once per decoder layer on the SAME mask features

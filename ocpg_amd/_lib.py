@@ -69,6 +69,7 @@ SIGNATURES = {
                                                              _vp, _vp, _int, _vp],
     "ocpg_win_attn_fwd": [_vp, _vp, _vp, ctypes.c_float] + [_int] * 5 + [_vp, _vp, _int, _vp],
     "ocpg_win_attn_bwd": [_vp, _vp, _vp, _vp, ctypes.c_float] + [_int] * 5 + [_vp] * 6 + [_int, _vp],
+    "ocpg_win_attn_bwd_mfma": [_vp, _vp, _vp, _vp, ctypes.c_float] + [_int] * 5 + [_vp] * 6 + [_int, _vp],
 }
 
 

@@ -19,7 +19,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
+
 #include "../../include/ocpg_hip.h"
+#include "win_attn_mfma.h"
 
 namespace {
 
@@ -294,6 +297,11 @@ inline int check_dims(int BW, int NW, int N, int H, int hd) {
   return 0;
 }
 
+inline bool mfma_enabled() {      // A/B switch, read per call: OCPG_WIN_ATTN_MFMA=0 keeps the fp32 vector-ALU kernels for bf16 / fp16 too
+  const char* e = std::getenv("OCPG_WIN_ATTN_MFMA");
+  return !(e && e[0] == '0');
+}
+
 }  // namespace
 
 extern "C" {
@@ -307,6 +315,8 @@ int ocpg_win_attn_fwd(const void* qkv, const float* biasT, const int* region, fl
   if (!out) return -1010;
   if (!lse) return -1011;
   hipStream_t st = (hipStream_t)stream;
+  if (mfma_enabled() && ocpg_win_mfma::supported(N, head_dim, dtype))
+    return ocpg_win_mfma::fwd(qkv, biasT, region, scale, BW, NW, N, H, out, lse, dtype, st);
   switch (dtype) {
     case 0: return fwd<float>(qkv, biasT, region, scale, BW, NW, N, H, out, lse, st);
     case 1: return fwd<__hip_bfloat16>(qkv, biasT, region, scale, BW, NW, N, H, out, lse, st);
@@ -335,6 +345,26 @@ int ocpg_win_attn_bwd(const void* qkv, const float* bias, const float* biasT, co
     case 2: return bwd<__half>(qkv, bias, biasT, region, scale, BW, NW, N, H, out, dout, lse, dqkv, Dbuf, dbiasT, st);
   }
   return -1017;
+}
+
+/* Matrix-core backward (csrc/win_attn_mfma.hip): same arguments, but the bias gradient leaves as dS [BW, H, N, N] in the storage dtype
+ * ((key, query) order, fully written; NULL when the bias needs no gradient) for the caller to sum over BW.  Returns -2000 when the shape /
+ * dtype is not served (or OCPG_WIN_ATTN_MFMA=0): the caller then uses ocpg_win_attn_bwd. */
+int ocpg_win_attn_bwd_mfma(const void* qkv, const float* bias, const float* biasT, const int* region, float scale, int BW, int NW, int N,
+                           int H, int head_dim, const void* out, const void* dout, const float* lse, void* dqkv, float* Dbuf, void* dS,
+                           int dtype, void* stream) {
+  if (int e = check_dims(BW, NW, N, H, head_dim)) return e;
+  if (!mfma_enabled() || !ocpg_win_mfma::supported(N, head_dim, dtype)) return -2000;
+  if (BW == 0) return 0;
+  if (!qkv) return -1001;
+  if (!bias) return -1002;
+  if (!biasT) return -1003;
+  if (!out) return -1011;
+  if (!dout) return -1012;
+  if (!lse) return -1013;
+  if (!dqkv) return -1014;
+  if (!Dbuf) return -1015;
+  return ocpg_win_mfma::bwd(qkv, bias, biasT, region, scale, BW, NW, N, H, out, dout, lse, dqkv, Dbuf, dS, dtype, (hipStream_t)stream);
 }
 
 }  // extern "C"

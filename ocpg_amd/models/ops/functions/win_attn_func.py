@@ -44,8 +44,22 @@ class WindowAttentionFunction(Function):
         dout = dout.to(qkv.dtype).contiguous()
         dqkv = torch.empty_like(qkv)
         dbuf = torch.empty_like(lse)
-        dbias_t = torch.zeros_like(bias_t) if ctx.needs_input_grad[1] else None
         region = ctx.region
+        if qkv.dtype != torch.float32:
+            # matrix-core kernels (csrc/win_attn_mfma.hip): dS leaves as a [BW, H, N, N] tensor in the storage dtype and is summed
+            # over the windows here (one streaming reduction instead of BW * H * N^2 float atomics)
+            ds = torch.empty((bw, h, n, n), dtype=qkv.dtype, device=qkv.device) if ctx.needs_input_grad[1] else None
+            with torch.cuda.device(qkv.device):
+                rc = lib().ocpg_win_attn_bwd_mfma(qkv.data_ptr(), bias.data_ptr(), bias_t.data_ptr(),
+                                                  region.data_ptr() if region is not None else None, ctx.scale, bw, ctx.num_windows, n, h, hd,
+                                                  out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), dbuf.data_ptr(),
+                                                  ds.data_ptr() if ds is not None else None, _DT[qkv.dtype], stream_ptr())
+            if rc == 0:
+                dbias = ds.sum(0, dtype=torch.float32).transpose(1, 2) if ds is not None else None
+                return dqkv, dbias, None, None, None
+            if rc != -2000:
+                check(rc, "ocpg_win_attn_bwd_mfma")
+        dbias_t = torch.zeros_like(bias_t) if ctx.needs_input_grad[1] else None
         with torch.cuda.device(qkv.device):
             check(lib().ocpg_win_attn_bwd(qkv.data_ptr(), bias.data_ptr(), bias_t.data_ptr(),
                                           region.data_ptr() if region is not None else None, ctx.scale, bw, ctx.num_windows, n, h, hd,
