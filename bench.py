@@ -173,7 +173,8 @@ class GraphStep:
         self.static = {}
         # capture on the warm-up stream: the library's hipBLASLt workspace is per (device, stream) and was allocated there
         # (a hipMalloc inside the capture would invalidate it)
-        with torch.cuda.graph(self.graph, stream=side):
+        # N > 1: RCCL's watchdog thread may poll events while we capture; only THIS thread's unsafe calls should invalidate the capture
+        with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local" if world > 1 else "global"):
             self.loss = forward_backward(model, criterion, NestedTensor(self.x.clone(), self.mask.clone()), text, targets, amp_dtype,
                                          self.num_boxes, keep=self.static)
         # memset nodes (torch's reduction semaphores) replay with a corrupted pattern on this ROCm: swap them for kernel nodes
@@ -421,6 +422,18 @@ def main():
     step, mode = None, "eager"
     if not a.eager and amp_dtype != torch.float16:       # fp16 needs the GradScaler's host-side skip logic: eager
         snapshot = {k: v.clone() for k, v in model.state_dict().items()}
+
+        def back_to_eager():
+            nonlocal_state["optimizer"] = make_optimizer(model, args)
+            model.load_state_dict(snapshot)                      # failed replays may have poisoned the weights
+            criterion.iter_device, criterion.iter = None, 0
+            try:
+                from ocpg_amd.models.matcher import raise_if_malformed_boxes
+                raise_if_malformed_boxes()
+            except AssertionError:
+                pass
+        nonlocal_state = {"optimizer": optimizer}
+        ok = 1
         try:
             torch.manual_seed(1234 + rank)
             model.zero_grad(set_to_none=True)
@@ -428,23 +441,25 @@ def main():
             model.zero_grad(set_to_none=True)
             criterion.iter = 0
             step = GraphStep(model, criterion, optimizer, make_samples, text, targets, args, amp_dtype, world)
-            step.check(eager_loss)
-            for _ in range(3):          # the instability shows after optimizer steps: exercise them before trusting the graph
-                if not bool(torch.isfinite(step())):
-                    raise RuntimeError("graph replay turned non-finite after an optimizer step")
-            mode = "hipgraph(fwd+criterion+bwd)"
+            step.check(eager_loss)                               # one replay, no collective
         except Exception as e:      # capture is an optimisation, never a requirement: report and run eagerly
             print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {str(e)[:200]}); running eagerly", file=sys.stderr, flush=True)
             torch.cuda.synchronize()
-            step = None
-            model.load_state_dict(snapshot)                      # the failed replays may have poisoned the weights
-            optimizer = make_optimizer(model, args)
-            criterion.iter_device, criterion.iter = None, 0
-            try:
-                from ocpg_amd.models.matcher import raise_if_malformed_boxes
-                raise_if_malformed_boxes()
-            except AssertionError:
-                pass
+            ok, step = 0, None
+        if world > 1:               # the launch mode must be the same on every rank (graph: one flat all-reduce; eager: DDP buckets)
+            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if ok and int(flag.item()) == 0:
+                print("[bench] another rank could not capture: running eagerly on all ranks", file=sys.stderr, flush=True)
+                ok, step = 0, None
+        if ok:
+            for _ in range(3):      # the round-1 instability showed after optimizer steps: exercise them before the timed region
+                if not bool(torch.isfinite(step())):
+                    raise RuntimeError("graph replay turned non-finite after an optimizer step")
+            mode = "hipgraph(fwd+criterion+bwd)"
+        else:
+            back_to_eager()
+            optimizer = nonlocal_state["optimizer"]
     if step is None:
         ddp_model = model
         if world > 1:
