@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
+
 #include "../../include/ocpg_hip.h"
 
 namespace {
@@ -27,11 +29,11 @@ namespace {
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 64, BN = 128, BK = 64, NT = 256;
+constexpr int BM = 64, BK = 64, NT = 256;        // BN (64 or 128) is a template parameter: 64 doubles the workgroups of the under-filled shapes
 constexpr int LDS_ROW = BK + 8;        // bf16 elements per LDS row (144 B: 16-B aligned, rows 4 banks apart)
 constexpr int SEGS = BK / 8;           // 16-B segments per staged row
 constexpr int ROWS_PER_PASS = NT / SEGS;
-constexpr int A_L = BM / ROWS_PER_PASS, B_L = BN / ROWS_PER_PASS;   // 16-B loads per thread per K step
+constexpr int A_L = BM / ROWS_PER_PASS;   // 16-B loads per thread per K step (B: BN / ROWS_PER_PASS)
 constexpr int NSETS = 2;               // register sets in flight
 
 struct ConvGeom {
@@ -58,11 +60,12 @@ __device__ __forceinline__ bool tap_source(const ConvGeom& g, int y, int x, int 
   }
 }
 
-template <bool DGRAD>
+template <bool DGRAD, int BN>
 __global__ __launch_bounds__(NT) void conv3x3_mfma(const __hip_bfloat16* __restrict__ x, const __hip_bfloat16* __restrict__ w,
                                                    const float* __restrict__ scale, const float* __restrict__ bias, int relu, ConvGeom g,
                                                    __hip_bfloat16* __restrict__ y) {
   __shared__ __attribute__((aligned(16))) short As[2][BM * LDS_ROW];
+  constexpr int B_L = BN / ROWS_PER_PASS, NJ = BN / 64, WN = BN / 2;      // a wave's tile: 32 rows x WN columns = NJ MFMA tiles
   __shared__ __attribute__((aligned(16))) short Bs[2][BN * LDS_ROW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;                 // wave tile: rows wm*32.., cols wn*64..
@@ -124,9 +127,9 @@ __global__ __launch_bounds__(NT) void conv3x3_mfma(const __hip_bfloat16* __restr
     for (int i = 0; i < B_L; ++i) *reinterpret_cast<uint4*>(&Bs[buf][(srow + i * ROWS_PER_PASS) * LDS_ROW + sseg * 8]) = bq[i];
   };
 
-  f32x16 acc[2];
+  f32x16 acc[NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NJ; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
@@ -136,8 +139,8 @@ __global__ __launch_bounds__(NT) void conv3x3_mfma(const __hip_bfloat16* __restr
     for (int kk = 0; kk < BK / 16; ++kk) {
       const bf16x8 a = *reinterpret_cast<const bf16x8*>(&As[buf][(wm * 32 + fr) * LDS_ROW + kk * 16 + fh * 8]);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(&Bs[buf][(wn * 64 + j * 32 + fr) * LDS_ROW + kk * 16 + fh * 8]);
+      for (int j = 0; j < NJ; ++j) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(&Bs[buf][(wn * WN + j * 32 + fr) * LDS_ROW + kk * 16 + fh * 8]);
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
       }
     }
@@ -163,8 +166,8 @@ __global__ __launch_bounds__(NT) void conv3x3_mfma(const __hip_bfloat16* __restr
   }
   // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+  for (int j = 0; j < NJ; ++j) {
+    const int col = n0 + wn * WN + j * 32 + (lane & 31);
     if (col >= g.Cout) continue;
     const float sv = scale ? scale[col] : 1.f, bv = bias ? bias[col] : 0.f;      // frozen-BN affine / conv bias in the epilogue
 #pragma unroll
@@ -175,6 +178,15 @@ __global__ __launch_bounds__(NT) void conv3x3_mfma(const __hip_bfloat16* __restr
       if (row < g.M) y[row * g.Cout + col] = __float2bfloat16(v);
     }
   }
+}
+
+// 64-column tiles when the 128-column grid would leave the chip under-filled or badly quantised (< 3 workgroups per CU):
+// layer3 of ResNet-101 at 10 frames of 384x640 is 150 x 2 = 300 workgroups on 256 CUs, layer4 38 x 4 = 152
+inline bool narrow_tiles(unsigned mtiles, int ncols) {
+  static const int mode = [] { const char* e = std::getenv("OCPG_CONV3X3_BN"); return e ? std::atoi(e) : 0; }();
+  if (mode == 64) return true;
+  if (mode == 128) return false;
+  return (long long)mtiles * ((ncols + 127) / 128) < 3 * 256;
 }
 
 }  // namespace
@@ -192,9 +204,13 @@ extern "C" int ocpg_conv3x3_mfma_fwd(const void* x, const void* w, const float* 
   ConvGeom g;
   g.N = N; g.H = (H - 1) / stride + 1; g.W = (W - 1) / stride + 1; g.C = Cin; g.Hs = H; g.Ws = W; g.Cout = Cout; g.stride = stride;
   g.M = (long long)N * g.H * g.W;
-  const dim3 grid((unsigned)((g.M + BM - 1) / BM), (unsigned)((Cout + BN - 1) / BN));
-  conv3x3_mfma<false><<<grid, NT, 0, (hipStream_t)stream>>>((const __hip_bfloat16*)x, (const __hip_bfloat16*)w, scale, bias, relu, g,
-                                                            (__hip_bfloat16*)y);
+  const unsigned mt = (unsigned)((g.M + BM - 1) / BM);
+  if (narrow_tiles(mt, Cout))
+    conv3x3_mfma<false, 64><<<dim3(mt, (unsigned)((Cout + 63) / 64)), NT, 0, (hipStream_t)stream>>>(
+        (const __hip_bfloat16*)x, (const __hip_bfloat16*)w, scale, bias, relu, g, (__hip_bfloat16*)y);
+  else
+    conv3x3_mfma<false, 128><<<dim3(mt, (unsigned)((Cout + 127) / 128)), NT, 0, (hipStream_t)stream>>>(
+        (const __hip_bfloat16*)x, (const __hip_bfloat16*)w, scale, bias, relu, g, (__hip_bfloat16*)y);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
@@ -211,9 +227,13 @@ extern "C" int ocpg_conv3x3_mfma_dgrad(const void* dy, const void* wT, int N, in
   ConvGeom g;
   g.N = N; g.H = H; g.W = W; g.C = Cout; g.Hs = (H - 1) / stride + 1; g.Ws = (W - 1) / stride + 1; g.Cout = Cin; g.stride = stride;
   g.M = (long long)N * H * W;
-  const dim3 grid((unsigned)((g.M + BM - 1) / BM), (unsigned)((Cin + BN - 1) / BN));
-  conv3x3_mfma<true><<<grid, NT, 0, (hipStream_t)stream>>>((const __hip_bfloat16*)dy, (const __hip_bfloat16*)wT, nullptr, nullptr, 0, g,
-                                                           (__hip_bfloat16*)dx);
+  const unsigned mt = (unsigned)((g.M + BM - 1) / BM);
+  if (narrow_tiles(mt, Cin))
+    conv3x3_mfma<true, 64><<<dim3(mt, (unsigned)((Cin + 63) / 64)), NT, 0, (hipStream_t)stream>>>(
+        (const __hip_bfloat16*)dy, (const __hip_bfloat16*)wT, nullptr, nullptr, 0, g, (__hip_bfloat16*)dx);
+  else
+    conv3x3_mfma<true, 128><<<dim3(mt, (unsigned)((Cin + 127) / 128)), NT, 0, (hipStream_t)stream>>>(
+        (const __hip_bfloat16*)dy, (const __hip_bfloat16*)wT, nullptr, nullptr, 0, g, (__hip_bfloat16*)dx);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
