@@ -140,10 +140,18 @@ class FusedCast(torch.autograd.Function):
         ctx.src_strides = [p.stride() for p in params]
         ctx.plan = plan
         if plan is not None:
-            return tuple(plan.cast_params())
-        outs = [torch.empty_like(p, dtype=dtype) for p in params]
-        torch._foreach_copy_(outs, list(params))
-        return tuple(outs)
+            outs = tuple(plan.cast_params())
+        else:
+            outs = [torch.empty_like(p, dtype=dtype) for p in params]
+            torch._foreach_copy_(outs, list(params))
+            outs = tuple(outs)
+        # A custom Function marks EVERY output as requiring grad when ANY input does.  The copies of frozen parameters (the
+        # ResNet stem and layer1, models/backbone.py:63-65) must stay non-differentiable, or autograd runs the backward of the
+        # frozen layers too (dgrad + wgrad of the three largest bottlenecks and the stem, then throws the results away).
+        frozen = [o for o, p in zip(outs, params) if not p.requires_grad]
+        if frozen:
+            ctx.mark_non_differentiable(*frozen)
+        return outs
 
     @staticmethod
     def backward(ctx, *grads):
