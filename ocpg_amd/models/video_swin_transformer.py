@@ -23,6 +23,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import amp_cache
+
 from ..util.misc import NestedTensor
 from .ops.functions.win_attn_func import window_attention
 from .position_encoding import build_position_encoding
@@ -50,9 +52,9 @@ class DropPath(nn.Module):
 class Mlp(nn.Module):
     def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
         super().__init__()
-        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+        self.fc1 = amp_cache.Linear(in_features, hidden_features or in_features)
         self.act = act_layer()
-        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+        self.fc2 = amp_cache.Linear(hidden_features or in_features, out_features or in_features)
         self.drop = nn.Dropout(drop)
 
     def forward(self, x):
@@ -117,9 +119,9 @@ class WindowAttention3D(nn.Module):
         rel[:, :, 0] *= (2 * wh - 1) * (2 * ww - 1)
         rel[:, :, 1] *= (2 * ww - 1)
         self.register_buffer("relative_position_index", rel.sum(-1))
-        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.qkv = amp_cache.Linear(dim, dim * 3, bias=qkv_bias)
         self.attn_drop = nn.Dropout(attn_drop)
-        self.proj = nn.Linear(dim, dim)
+        self.proj = amp_cache.Linear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
         nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
 
@@ -211,7 +213,7 @@ class PatchMerging(nn.Module):
     def __init__(self, dim, norm_layer=nn.LayerNorm):
         super().__init__()
         self.dim = dim
-        self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
+        self.reduction = amp_cache.Linear(4 * dim, 2 * dim, bias=False)
         self.norm = norm_layer(4 * dim)
 
     def forward(self, x):
