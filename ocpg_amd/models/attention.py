@@ -36,13 +36,13 @@ class MultiheadAttention(nn.Module):
             if query is key:
                 wqk, wv = w.split([2 * C, C])
                 bqk, bv = b.split([2 * C, C])
-                qk = F.linear(query, wqk, bqk)
+                qk = amp_cache.linear(query, wqk, bqk)
                 q, k = qk[..., :C], qk[..., C:]
             else:
                 wq, wk, wv = w.chunk(3)
                 bq, bk, bv = b.chunk(3)
-                q, k = F.linear(query, wq, bq), F.linear(key, wk, bk)
-            v = F.linear(value, wv, bv)
+                q, k = amp_cache.linear(query, wq, bq), amp_cache.linear(key, wk, bk)
+            v = amp_cache.linear(value, wv, bv)
             o = attn_smallk_func.attention(q, k, v, key_padding_mask, hd ** -0.5, H, self.dropout if self.training else 0.0)
             if o is not None:
                 return self.out_proj(o)

@@ -257,6 +257,38 @@ def test_lfm_fused_spectral_gate(dev):
         assert (u - v).abs().max().item() <= 2e-5 * v.abs().max().item() + 1e-7, ((u - v).abs().max().item(), v.abs().max().item())
 
 
+@pytest.mark.parametrize("xdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("r,cin,cout,bias", [(50, 256, 256, True), (50, 256, 4, True), (200, 256, 4416, True), (10, 256, 1, False),
+                                             (18, 256, 512, True), (50, 256, 384, True), (130, 128, 70, True), (1, 64, 64, True)])
+def test_small_linear_kernel(dev, xdt, r, cin, cout, bias):
+    """csrc/small_linear.hip (few-row Linear, one launch each way) == autocast's cast + addmm and its autograd backward: same bf16
+    operands, fp32 accumulation -> y, gx (in x's dtype), gw, gb to one bf16 ulp of the fp32 result."""
+    from ocpg_amd.models import amp_cache
+    g = torch.Generator(device=dev).manual_seed(r * 131 + cout)
+    x = torch.randn(2, r // 2 if r % 2 == 0 else r, cin, device=dev, generator=g).to(xdt)
+    x = x if r % 2 == 0 else x[:1]
+    w = (torch.randn(cout, cin, device=dev, generator=g) * cin ** -0.5).bfloat16()
+    b = torch.randn(cout, device=dev, generator=g).bfloat16() if bias else None
+    go = torch.randn(*x.shape[:-1], cout, device=dev, generator=g).bfloat16()
+    res = []
+    for mine in (True, False):
+        xi, wi = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        bi = b.clone().requires_grad_(True) if bias else None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            if mine:
+                assert amp_cache._small_linear_ok(xi, wi, bi)
+                y = amp_cache.SmallLinearFunction.apply(xi, wi, bi)
+            else:
+                y = torch.nn.functional.linear(xi, wi, bi)
+        assert y.dtype == torch.bfloat16
+        grads = torch.autograd.grad((y.float() * go.float()).sum(), [xi, wi] + ([bi] if bias else []))
+        assert grads[0].dtype == xdt
+        res.append([y.float()] + [t.float() for t in grads])
+    for name, a, b_ in zip(("y", "gx", "gw", "gb"), res[0], res[1]):
+        tol = 2 ** -7 * b_.abs().max().item() + 1e-6
+        assert (a - b_).abs().max().item() <= tol, (name, (a - b_).abs().max().item(), b_.abs().max().item())
+
+
 @pytest.mark.parametrize("amp", [None, torch.bfloat16])
 def test_lfm_channels_last_gate(dev, amp):
     """LFM with the gate output / inverse-FFT input in channels-last memory (csrc/spectral.hip c2p / p2c, 1x1 convs as GEMMs)
