@@ -296,12 +296,14 @@ int ocpg_window_means3x3_bwd(const float* gm, long long planes, int h, int w, fl
 
 /* nn.Linear over FEW rows (decoder layers, box / class heads, controller, LFM coefficient MLPs: models/deformable_transformer.py:
  * 313-336, models/ocpg.py:83-110) under autocast, one launch forward and ONE launch backward (csrc/small_linear.hip):
- *   fwd: y [R, Cout] bf16 = x [R, Cin] (fp32 when x_f32 != 0, else bf16) . w [Cout, Cin]^T (bf16) + b [Cout] (bf16 or NULL)
- *   bwd: gx [R, Cin] in x's dtype (NULL: not needed), gw [Cout, Cin] bf16, gb [Cout] bf16 (NULL: no bias) from gy [R, Cout]
+ *   fwd: y [R, Cout] bf16 = act(x [R, Cin] (fp32 when x_f32 != 0, else bf16) . w [Cout, Cin]^T (bf16) + b [Cout] (bf16 or NULL)),
+ *        act = ReLU when relu != 0 (the MLPs' `F.relu(layer(x))`, models/ocpg.py:53-58)
+ *   bwd: gx [R, Cin] in x's dtype (NULL: not needed), gw [Cout, Cin] bf16, gb [Cout] bf16 (NULL: no bias) from gy [R, Cout];
+ *        y_relu = the forward's output when it applied the ReLU (gy is masked where y <= 0), else NULL
  * Cin must be a multiple of 64 and R <= 4096; otherwise -2000 (the caller keeps its GEMM path). */
-int ocpg_small_linear_fwd(const void* x, int x_f32, const void* w, const void* b, int R, int Cin, int Cout, void* y, void* stream);
-int ocpg_small_linear_bwd(const void* gy, int gy_f32, const void* x, int x_f32, const void* w, int R, int Cin, int Cout, void* gx, void* gw,
-                          void* gb, void* stream);
+int ocpg_small_linear_fwd(const void* x, int x_f32, const void* w, const void* b, int R, int Cin, int Cout, int relu, void* y, void* stream);
+int ocpg_small_linear_bwd(const void* gy, int gy_f32, const void* x, int x_f32, const void* w, const void* y_relu, int R, int Cin, int Cout,
+                          void* gx, void* gw, void* gb, void* stream);
 
 /* Whole-step HIP-graph capture support (no reference counterpart: the reference launches eagerly).  Replaces every memset node of
  * a captured, not yet instantiated hipGraph_t by a kernel node with the same destination, value, extent and edges: with the HIP

@@ -35,8 +35,8 @@ SIGNATURES = {
     "ocpg_gemm_plans": [],
     "ocpg_window_means3x3_fwd": [_vp, ctypes.c_longlong, _int, _int, _int, _vp, _vp],
     "ocpg_window_means3x3_bwd": [_vp, ctypes.c_longlong, _int, _int, _vp, _vp],
-    "ocpg_small_linear_fwd": [_vp, _int, _vp, _vp, _int, _int, _int, _vp, _vp],
-    "ocpg_small_linear_bwd": [_vp, _int, _vp, _int, _vp, _int, _int, _int, _vp, _vp, _vp, _vp],
+    "ocpg_small_linear_fwd": [_vp, _int, _vp, _vp, _int, _int, _int, _int, _vp, _vp],
+    "ocpg_small_linear_bwd": [_vp, _int, _vp, _int, _vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp],
     "ocpg_graph_replace_memsets": [_vp, _vp],
     "ocpg_graph_stats": [_vp, _vp],
     "ocpg_graph_memcpy_nodes": [_vp, _vp, _int],

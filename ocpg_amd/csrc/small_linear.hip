@@ -34,7 +34,7 @@ __device__ __forceinline__ short ld_el(const void* p, int is_f32, long long ld, 
 
 // 16 consecutive elements of row `row` starting at column `col` (fp32 or bf16 storage) as bf16 bits, zeros outside the matrix;
 // 16-byte loads when the run is inside and aligned
-__device__ __forceinline__ void ld16(short (&v)[16], const void* p, int is_f32, long long ld, int row, int col, int rows, int cols) {
+__device__ __forceinline__ void ld16_raw(short (&v)[16], const void* p, int is_f32, long long ld, int row, int col, int rows, int cols) {
   if (row < rows && col + 16 <= cols && ((ld | col) & 7) == 0) {
     if (is_f32) {
       const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + row * ld + col);
@@ -55,11 +55,24 @@ __device__ __forceinline__ void ld16(short (&v)[16], const void* p, int is_f32, 
   }
 }
 
+// the same with an optional ReLU mask: `mask` = the bf16 output y of a fused ReLU (same shape as p): gy is zeroed where y <= 0
+__device__ __forceinline__ void ld16(short (&v)[16], const void* p, int is_f32, long long ld, int row, int col, int rows, int cols,
+                                     const short* mask = nullptr) {
+  ld16_raw(v, p, is_f32, ld, row, col, rows, cols);
+  if (mask) {
+    short m[16];
+    ld16_raw(m, mask, 0, ld, row, col, rows, cols);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = b2f(m[u]) > 0.f ? v[u] : (short)0;
+  }
+}
+
 // stage a T x T tile of a row-major matrix into LDS as [tile row][tile col] (reduction axis = columns)
-__device__ __forceinline__ void stage_plain(short* dst, const void* src, int is_f32, long long ld, int r0, int c0, int rows, int cols) {
+__device__ __forceinline__ void stage_plain(short* dst, const void* src, int is_f32, long long ld, int r0, int c0, int rows, int cols,
+                                            const short* mask = nullptr) {
   const int row = threadIdx.x >> 2, seg = threadIdx.x & 3;
   short v[16];
-  ld16(v, src, is_f32, ld, r0 + row, c0 + seg * 16, rows, cols);
+  ld16(v, src, is_f32, ld, r0 + row, c0 + seg * 16, rows, cols, mask);
   bf16x8 a, b;
 #pragma unroll
   for (int u = 0; u < 8; ++u) { a[u] = v[u]; b[u] = v[8 + u]; }
@@ -68,10 +81,11 @@ __device__ __forceinline__ void stage_plain(short* dst, const void* src, int is_
 }
 
 // stage a T x T tile TRANSPOSED: LDS [tile col][tile row] (reduction axis = rows of the source)
-__device__ __forceinline__ void stage_transposed(short* dst, const void* src, int is_f32, long long ld, int r0, int c0, int rows, int cols) {
+__device__ __forceinline__ void stage_transposed(short* dst, const void* src, int is_f32, long long ld, int r0, int c0, int rows, int cols,
+                                                 const short* mask = nullptr) {
   const int row = threadIdx.x >> 2, seg = threadIdx.x & 3;
   short v[16];
-  ld16(v, src, is_f32, ld, r0 + row, c0 + seg * 16, rows, cols);
+  ld16(v, src, is_f32, ld, r0 + row, c0 + seg * 16, rows, cols, mask);
 #pragma unroll
   for (int u = 0; u < 16; ++u) dst[(seg * 16 + u) * LROW + row] = v[u];
 }
@@ -89,7 +103,8 @@ __device__ __forceinline__ f32x16 tile_mma(const short* As, const short* Bs, f32
 }
 
 // store the wave's 32 x 32 block of C[m0.., n0..] (row-major [M, N], fp32 or bf16), + optional per-column bias
-__device__ __forceinline__ void store_tile(void* C, int out_f32, long long ld, int m0, int n0, int M, int N, f32x16 acc, const short* bias) {
+__device__ __forceinline__ void store_tile(void* C, int out_f32, long long ld, int m0, int n0, int M, int N, f32x16 acc, const short* bias,
+                                           int relu = 0) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave & 1, wn = wave >> 1;
   const int col = n0 + wn * 32 + (lane & 31);
   if (col >= N) return;
@@ -98,7 +113,8 @@ __device__ __forceinline__ void store_tile(void* C, int out_f32, long long ld, i
   for (int i = 0; i < 16; ++i) {
     const int row = m0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
     if (row < M) {
-      const float v = acc[i] + bv;
+      float v = acc[i] + bv;
+      if (relu) v = fmaxf(v, 0.f);
       if (out_f32) reinterpret_cast<float*>(C)[row * ld + col] = v;
       else reinterpret_cast<short*>(C)[row * ld + col] = f2b(v);
     }
@@ -106,7 +122,7 @@ __device__ __forceinline__ void store_tile(void* C, int out_f32, long long ld, i
 }
 
 __global__ __launch_bounds__(NT) void sl_fwd(const void* __restrict__ x, int x_f32, const short* __restrict__ w, const short* __restrict__ b,
-                                             int R, int Cin, int Cout, short* __restrict__ y) {
+                                             int R, int Cin, int Cout, int relu, short* __restrict__ y) {
   __shared__ __attribute__((aligned(16))) short As[T * LROW], Bs[T * LROW];
   const int n0 = blockIdx.x * T, m0 = blockIdx.y * T;
   f32x16 acc;
@@ -119,13 +135,13 @@ __global__ __launch_bounds__(NT) void sl_fwd(const void* __restrict__ x, int x_f
     acc = tile_mma(As, Bs, acc);
     __syncthreads();
   }
-  store_tile(y, 0, Cout, m0, n0, R, Cout, acc, b);
+  store_tile(y, 0, Cout, m0, n0, R, Cout, acc, b, relu);
 }
 
 // blocks [0, n_dx): gx tiles (M = R, N = Cin, K = Cout);  blocks [n_dx, ..): gw tiles (M = Cout, N = Cin, K = R) + gb from the n-tile 0 column
 __global__ __launch_bounds__(NT) void sl_bwd(const void* __restrict__ gy, int gy_f32, const void* __restrict__ x, int x_f32,
-                                             const short* __restrict__ w, int R, int Cin, int Cout, int n_dx, int need_gx, void* __restrict__ gx,
-                                             short* __restrict__ gw, short* __restrict__ gb) {
+                                             const short* __restrict__ w, const short* __restrict__ ymask, int R, int Cin, int Cout, int n_dx,
+                                             int need_gx, void* __restrict__ gx, short* __restrict__ gw, short* __restrict__ gb) {
   __shared__ __attribute__((aligned(16))) short As[T * LROW], Bs[T * LROW];
   const int ntn = (Cin + T - 1) / T;
   f32x16 acc;
@@ -135,7 +151,7 @@ __global__ __launch_bounds__(NT) void sl_bwd(const void* __restrict__ gy, int gy
     if (!need_gx) return;
     const int m0 = (blockIdx.x / ntn) * T, n0 = (blockIdx.x % ntn) * T;
     for (int k0 = 0; k0 < Cout; k0 += T) {
-      stage_plain(As, gy, gy_f32, Cout, m0, k0, R, Cout);               // A[m = r][k = co]
+      stage_plain(As, gy, gy_f32, Cout, m0, k0, R, Cout, ymask);        // A[m = r][k = co]
       stage_transposed(Bs, w, 0, Cin, k0, n0, Cout, Cin);               // B[n = ci][k = co] = w[co][ci]
       __syncthreads();
       acc = tile_mma(As, Bs, acc);
@@ -148,7 +164,7 @@ __global__ __launch_bounds__(NT) void sl_bwd(const void* __restrict__ gy, int gy
     const bool do_bias = gb && (t % ntn) == 0;
     float bsum = 0.f;
     for (int k0 = 0; k0 < R; k0 += T) {
-      stage_transposed(As, gy, gy_f32, Cout, k0, m0, R, Cout);          // A[m = co][k = r] = gy[r][co]
+      stage_transposed(As, gy, gy_f32, Cout, k0, m0, R, Cout, ymask);   // A[m = co][k = r] = gy[r][co]
       stage_transposed(Bs, x, x_f32, Cin, k0, n0, R, Cin);              // B[n = ci][k = r] = x[r][ci]
       __syncthreads();
       acc = tile_mma(As, Bs, acc);
@@ -172,8 +188,9 @@ inline int status() {
 
 extern "C" {
 
-/* y [R, Cout] bf16 = x [R, Cin] (fp32: x_f32 != 0, else bf16) . w[Cout, Cin]^T (bf16) + b [Cout] (bf16 or NULL).  -2000: not served. */
-int ocpg_small_linear_fwd(const void* x, int x_f32, const void* w, const void* b, int R, int Cin, int Cout, void* y, void* stream) {
+/* y [R, Cout] bf16 = act(x [R, Cin] (fp32: x_f32 != 0, else bf16) . w[Cout, Cin]^T (bf16) + b [Cout] (bf16 or NULL)), act = ReLU when
+ * relu != 0.  -2000: not served. */
+int ocpg_small_linear_fwd(const void* x, int x_f32, const void* w, const void* b, int R, int Cin, int Cout, int relu, void* y, void* stream) {
   if (R < 0 || Cin <= 0 || Cout <= 0) return -1005;
   if (Cin % T != 0 || R > 4096) return -2000;
   if (R == 0) return 0;
@@ -181,13 +198,14 @@ int ocpg_small_linear_fwd(const void* x, int x_f32, const void* w, const void* b
   if (!w) return -1003;
   if (!y) return -1008;
   sl_fwd<<<dim3((Cout + T - 1) / T, (R + T - 1) / T), NT, 0, (hipStream_t)stream>>>(x, x_f32, (const short*)w, (const short*)b, R, Cin, Cout,
-                                                                                    (short*)y);
+                                                                                    relu, (short*)y);
   return status();
 }
 
-/* gx [R, Cin] (x's dtype; NULL: not needed), gw [Cout, Cin] bf16, gb [Cout] bf16 (NULL: no bias) from gy [R, Cout] (fp32 / bf16). */
-int ocpg_small_linear_bwd(const void* gy, int gy_f32, const void* x, int x_f32, const void* w, int R, int Cin, int Cout, void* gx, void* gw,
-                          void* gb, void* stream) {
+/* gx [R, Cin] (x's dtype; NULL: not needed), gw [Cout, Cin] bf16, gb [Cout] bf16 (NULL: no bias) from gy [R, Cout] (fp32 / bf16);
+ * y_relu = the forward's output when it applied the ReLU (gy is masked where y <= 0), else NULL. */
+int ocpg_small_linear_bwd(const void* gy, int gy_f32, const void* x, int x_f32, const void* w, const void* y_relu, int R, int Cin, int Cout,
+                          void* gx, void* gw, void* gb, void* stream) {
   if (R < 0 || Cin <= 0 || Cout <= 0) return -1006;
   if (Cin % T != 0 || R > 4096) return -2000;
   if (!gy) return -1001;
@@ -196,8 +214,8 @@ int ocpg_small_linear_bwd(const void* gy, int gy_f32, const void* x, int x_f32, 
   if (!gw) return -1010;
   const int n_dx = gx ? ((R + T - 1) / T) * ((Cin + T - 1) / T) : 0;
   const int n_dw = ((Cout + T - 1) / T) * ((Cin + T - 1) / T);
-  sl_bwd<<<n_dx + n_dw, NT, 0, (hipStream_t)stream>>>(gy, gy_f32, x, x_f32, (const short*)w, R, Cin, Cout, n_dx, gx != nullptr, gx, (short*)gw,
-                                                      (short*)gb);
+  sl_bwd<<<n_dx + n_dw, NT, 0, (hipStream_t)stream>>>(gy, gy_f32, x, x_f32, (const short*)w, (const short*)y_relu, R, Cin, Cout, n_dx,
+                                                      gx != nullptr, gx, (short*)gw, (short*)gb);
   return status();
 }
 

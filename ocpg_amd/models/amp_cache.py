@@ -269,7 +269,7 @@ class SmallLinearFunction(torch.autograd.Function):
     gradient in x's dtype, weight gradient, bias gradient) instead of cast + addmm and mm + mm + sum + cast."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, relu=False):
         from .._lib import check, lib
         k, co = x.shape[-1], w.shape[0]
         x2 = x.reshape(-1, k)
@@ -277,15 +277,20 @@ class SmallLinearFunction(torch.autograd.Function):
             x2 = x2.contiguous()
         y = torch.empty((*x.shape[:-1], co), dtype=torch.bfloat16, device=x.device)    # not a view: an in-place ReLU may follow
         check(lib().ocpg_small_linear_fwd(x2.data_ptr(), int(x2.dtype == torch.float32), w.data_ptr(), None if b is None else b.data_ptr(),
-                                          x2.shape[0], k, co, y.data_ptr(), torch.cuda.current_stream().cuda_stream), "ocpg_small_linear_fwd")
-        ctx.save_for_backward(x2, w)
-        ctx.x_shape, ctx.has_bias = x.shape, b is not None
+                                          x2.shape[0], k, co, int(relu), y.data_ptr(), torch.cuda.current_stream().cuda_stream),
+              "ocpg_small_linear_fwd")
+        if relu:
+            ctx.save_for_backward(x2, w, y)
+        else:
+            ctx.save_for_backward(x2, w)
+        ctx.x_shape, ctx.has_bias, ctx.relu = x.shape, b is not None, bool(relu)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         from .._lib import check, lib
-        x2, w = ctx.saved_tensors
+        x2, w = ctx.saved_tensors[:2]
+        ymask = ctx.saved_tensors[2] if ctx.relu else None
         co, k = w.shape
         g2 = gy.reshape(-1, co)
         if g2.dtype not in (torch.float32, torch.bfloat16):
@@ -296,17 +301,25 @@ class SmallLinearFunction(torch.autograd.Function):
         gw = torch.empty_like(w)
         gb = torch.empty(co, dtype=torch.bfloat16, device=w.device) if ctx.has_bias else None
         check(lib().ocpg_small_linear_bwd(g2.data_ptr(), int(g2.dtype == torch.float32), x2.data_ptr(), int(x2.dtype == torch.float32), w.data_ptr(),
-                                          x2.shape[0], k, co, None if gx is None else gx.data_ptr(), gw.data_ptr(),
-                                          None if gb is None else gb.data_ptr(), torch.cuda.current_stream().cuda_stream), "ocpg_small_linear_bwd")
-        return (None if gx is None else gx.view(ctx.x_shape)), gw, gb
+                                          None if ymask is None else ymask.data_ptr(), x2.shape[0], k, co,
+                                          None if gx is None else gx.data_ptr(), gw.data_ptr(), None if gb is None else gb.data_ptr(),
+                                          torch.cuda.current_stream().cuda_stream), "ocpg_small_linear_bwd")
+        return (None if gx is None else gx.view(ctx.x_shape)), gw, gb, None
 
 
 def _small_linear_ok(x, w, b):
     k = x.shape[-1]
     return (SMALL_LINEAR and x.is_cuda and torch.is_grad_enabled() and torch.is_autocast_enabled("cuda")
-            and torch.get_autocast_dtype("cuda") == torch.bfloat16 and w.dim() == 2 and k % 64 == 0 and k <= 512
+            and torch.get_autocast_dtype("cuda") == torch.bfloat16 and w.dim() == 2 and k % 64 == 0 and k <= int(os.environ.get("OCPG_SMALL_LINEAR_MAXK", "512"))
             and x.numel() <= 1024 * k and x.dtype in (torch.float32, torch.bfloat16) and w.dtype == torch.bfloat16 and w.is_contiguous()
             and (b is None or (b.dtype == torch.bfloat16 and b.is_contiguous())))
+
+
+def linear_relu(x, w, b):
+    """relu(linear(x, w, b)); few rows under bf16 autocast: ONE launch (the ReLU rides in the GEMM epilogue, its mask in the backward's loads)."""
+    if _small_linear_ok(x, w, b):
+        return SmallLinearFunction.apply(x, w, b, True)
+    return F.relu(linear(x, w, b))
 
 
 def linear(x, w, b):

@@ -52,9 +52,10 @@ class MLP(nn.Module):
 
     def forward(self, x):
         for i, layer in enumerate(self.layers):
-            x = layer(x)
             if i < self.num_layers - 1:
-                x = F.relu(x)
+                x = amp_cache.linear_relu(x, amp_cache.lookup(layer.weight), None if layer.bias is None else amp_cache.lookup(layer.bias))
+            else:
+                x = layer(x)
         return x
 
 

@@ -257,10 +257,11 @@ def test_lfm_fused_spectral_gate(dev):
         assert (u - v).abs().max().item() <= 2e-5 * v.abs().max().item() + 1e-7, ((u - v).abs().max().item(), v.abs().max().item())
 
 
+@pytest.mark.parametrize("relu", [False, True])
 @pytest.mark.parametrize("xdt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("r,cin,cout,bias", [(50, 256, 256, True), (50, 256, 4, True), (200, 256, 4416, True), (10, 256, 1, False),
                                              (18, 256, 512, True), (50, 256, 384, True), (130, 128, 70, True), (1, 64, 64, True)])
-def test_small_linear_kernel(dev, xdt, r, cin, cout, bias):
+def test_small_linear_kernel(dev, xdt, r, cin, cout, bias, relu):
     """csrc/small_linear.hip (few-row Linear, one launch each way) == autocast's cast + addmm and its autograd backward: same bf16
     operands, fp32 accumulation -> y, gx (in x's dtype), gw, gb to one bf16 ulp of the fp32 result."""
     from ocpg_amd.models import amp_cache
@@ -277,9 +278,10 @@ def test_small_linear_kernel(dev, xdt, r, cin, cout, bias):
         with torch.autocast("cuda", dtype=torch.bfloat16):
             if mine:
                 assert amp_cache._small_linear_ok(xi, wi, bi)
-                y = amp_cache.SmallLinearFunction.apply(xi, wi, bi)
+                y = amp_cache.SmallLinearFunction.apply(xi, wi, bi, relu)
             else:
                 y = torch.nn.functional.linear(xi, wi, bi)
+                y = torch.relu(y) if relu else y
         assert y.dtype == torch.bfloat16
         grads = torch.autograd.grad((y.float() * go.float()).sum(), [xi, wi] + ([bi] if bias else []))
         assert grads[0].dtype == xdt
