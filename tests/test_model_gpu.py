@@ -926,3 +926,71 @@ def test_conv3x3_mfma_kernel(dev, n, c, co, h, w, stride, relu):
     assert rel(gx, gxr) <= 1.5e-2, rel(gx, gxr)
     assert rel(gw, gwr) <= 1.5e-2, rel(gw, gwr)
     assert (y.float() - yr).abs().max().item() <= 2e-2 * yr.abs().max().item() + 1e-3
+
+
+@pytest.mark.timeout(900)
+def test_full_size_step_vs_oracle(dev):
+    """BASELINE config #2 at FULL size (ResNet-101, 4+4 layers, 5 queries, one clip of 5 x 384 x 640, fp32, dropout off): the product's
+    forward + criterion on the GPU against oracle/ocpg_ref.py (the CPU restatement of the reference, pinned by the golden vectors) with
+    the same weights and inputs: mask logits, boxes, class logits, matcher indices (bit-exact) and every loss term."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p_ in (root, os.path.join(root, "tests", "golden")):
+        if p_ not in sys.path:
+            sys.path.insert(0, p_)
+    import bench
+    import synth
+    from oracle import ocpg_ref
+    from ocpg_amd.models import build_model
+    from ocpg_amd.models.text_encoder.text_encoder import PrecomputedText
+    from ocpg_amd.util.misc import NestedTensor
+    T, H, W = 5, 384, 640
+    args = bench.model_args(dev, "resnet101", amp=False)
+    args.dropout = 0.0
+    model, crit, _ = build_model(args)
+    sd = synth.synth_state_dict(synth.shapes_of(model), seed=7)
+    missing = model.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys and not missing.missing_keys
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if hasattr(m, "dropout_p"):
+            m.dropout_p = 0.0
+    model.to(dev), crit.to(dev)
+    model.train(), crit.train()
+    g = torch.Generator().manual_seed(3)
+    clip = torch.randn(1, T, 3, H, W, generator=g)
+    mask = torch.zeros(1, T, H, W, dtype=torch.bool)
+    feats, sent = torch.randn(1, 9, 768, generator=g), torch.randn(1, 768, generator=g)
+    pad = torch.zeros(1, 9, dtype=torch.bool)
+    targets = synth.synthetic_targets(1, T, H, W)
+    # ---- oracle, CPU
+    P = {k: v.clone() for k, v in sd.items()}
+    cfg = ocpg_ref.cfg_from_args(bench.model_args("cpu", "resnet101", amp=False))
+    with torch.no_grad():
+        o_out, o_losses, o_total = ocpg_ref.train_step_loss(P, cfg, clip, mask, (feats, sent, pad), targets)
+    # ---- product, GPU
+    tg = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in t.items()} for t in targets]
+    crit.iter = 0
+    with torch.no_grad():
+        out = model(NestedTensor(clip.to(dev), mask.to(dev)), PrecomputedText(feats.to(dev), sent.to(dev), pad.to(dev)), tg)
+        losses, *_ = crit(out, tg)
+        total = sum(losses[k] * crit.weight_dict[k] for k in losses if k in crit.weight_dict)
+    # matcher indices: bit-exact
+    assert [int(i[0].flatten()[0]) for i in out["main_matcher_index"]] == [int(v) for v in o_out["main_idx"].tolist()]
+    for layer_idx, want_idx in zip(out["aux_matcher_index"], o_out["aux_idx"]):
+        assert [int(i[0].flatten()[0]) for i in layer_idx] == [int(v) for v in want_idx.tolist()]
+    for name in ("pred_logits", "pred_boxes", "pred_masks", "pred_masks_low"):
+        a, b_ = out[name].float().cpu(), o_out[name].float()
+        assert a.shape == b_.shape, (name, a.shape, b_.shape)
+        err, scale = (a - b_).abs().max().item(), b_.abs().max().item()
+        print(f"{name}: max|err| {err:.3e} at max|ref| {scale:.3e}")
+        assert err <= 1e-3 + 2e-5 * scale, (name, err, scale)           # north star: mask logits <= 1e-3 (fp32), plus rounding at large magnitudes
+    bad = []
+    for k, v in o_losses.items():
+        a = float(losses[k])
+        if abs(a - float(v)) > 2e-4 * abs(float(v)) + 1e-6:
+            bad.append((k, a, float(v)))
+    assert not bad, bad[:6]
+    assert abs(float(total) - float(o_total)) <= 1e-4 * abs(float(o_total)), (float(total), float(o_total))
