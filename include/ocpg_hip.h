@@ -305,6 +305,16 @@ int ocpg_small_linear_fwd(const void* x, int x_f32, const void* w, const void* b
 int ocpg_small_linear_bwd(const void* gy, int gy_f32, const void* x, int x_f32, const void* w, const void* y_relu, int R, int Cin, int Cout,
                           void* gx, void* gw, void* gb, void* stream);
 
+/* nn.LayerNorm over the last axis of a token matrix with low-precision input / output (Video-Swin blocks: norm1, norm2,
+ * PatchMerging.norm -- models/video_swin_transformer.py:194,201,225): x [rows, C] with storage code x_f32 (1 fp32, 0 bf16, 2 fp16),
+ * gamma / beta fp32 [C], y with storage code y_f32, mean / rstd [rows] fp32 kept for the backward; bwd: dx with code dx_f32, part_g / part_b
+ * [ocpg_layernorm_blocks(rows), C] fp32 per-workgroup partial sums of dgamma / dbeta (the caller sums them).  C <= 1024, else -2000. */
+int ocpg_layernorm_blocks(long long rows);
+int ocpg_layernorm_fwd(const void* x, int x_f32, const float* gamma, const float* beta, long long rows, int C, float eps, void* y, int y_f32,
+                       float* mean, float* rstd, void* stream);
+int ocpg_layernorm_bwd(const void* gy, int gy_f32, const void* x, int x_f32, const float* gamma, const float* mean, const float* rstd,
+                       long long rows, int C, void* dx, int dx_f32, float* part_g, float* part_b, void* stream);
+
 /* Whole-step HIP-graph capture support (no reference counterpart: the reference launches eagerly).  Replaces every memset node of
  * a captured, not yet instantiated hipGraph_t by a kernel node with the same destination, value, extent and edges: with the HIP
  * runtime of ROCm 7.x a captured hipMemsetAsync writes a stale pattern from the second launch of the instantiated graph on

@@ -1,0 +1,58 @@
+"""Autograd binding of csrc/layernorm.hip: LayerNorm with low-precision input / output in one pass each way."""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from ...._lib import check, lib
+
+_CODE = {torch.float32: 1, torch.bfloat16: 0, torch.float16: 2}
+
+
+class LayerNormLP(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype):
+        c = x.shape[-1]
+        x2 = x.reshape(-1, c)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        rows = x2.shape[0]
+        y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        check(lib().ocpg_layernorm_fwd(x2.data_ptr(), _CODE[x2.dtype], weight.data_ptr(), bias.data_ptr(), rows, c, float(eps), y.data_ptr(),
+                                       _CODE[out_dtype], mean.data_ptr(), rstd.data_ptr(), torch.cuda.current_stream().cuda_stream), "ocpg_layernorm_fwd")
+        ctx.save_for_backward(x2, weight, mean, rstd)
+        ctx.x_shape = x.shape
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x2, weight, mean, rstd = ctx.saved_tensors
+        rows, c = x2.shape
+        g2 = gy.reshape(rows, c)
+        if g2.dtype not in _CODE:
+            g2 = g2.float()
+        if not g2.is_contiguous():
+            g2 = g2.contiguous()
+        dx = torch.empty_like(x2)
+        nb = lib().ocpg_layernorm_blocks(rows)
+        part = torch.empty((2, nb, c), dtype=torch.float32, device=x2.device)
+        check(lib().ocpg_layernorm_bwd(g2.data_ptr(), _CODE[g2.dtype], x2.data_ptr(), _CODE[x2.dtype], weight.data_ptr(), mean.data_ptr(),
+                                       rstd.data_ptr(), rows, c, dx.data_ptr(), _CODE[dx.dtype], part[0].data_ptr(), part[1].data_ptr(),
+                                       torch.cuda.current_stream().cuda_stream), "ocpg_layernorm_bwd")
+        dgb = part.sum(1)                   # one reduction for both
+        return dx.view(ctx.x_shape), dgb[0], dgb[1], None, None
+
+
+class LayerNorm(torch.nn.LayerNorm):
+    """nn.LayerNorm (same parameters / state_dict); on the GPU under bf16 / fp16 autocast, for a 1-D normalized_shape <= 1024 with fp32
+    affine parameters, one HIP pass each way that reads x in its own dtype and writes the output in the autocast dtype (what the
+    following Linear consumes) instead of cast + fp32 layer_norm + cast."""
+
+    def forward(self, x):
+        if (x.is_cuda and torch.is_autocast_enabled("cuda") and len(self.normalized_shape) == 1 and self.normalized_shape[0] <= 1024
+                and self.elementwise_affine and self.bias is not None and x.dtype in _CODE and self.weight.dtype == torch.float32
+                and x.numel() > 0):
+            return LayerNormLP.apply(x, self.weight, self.bias, self.eps, torch.get_autocast_dtype("cuda"))
+        return super().forward(x)

@@ -27,6 +27,7 @@ from . import amp_cache
 
 from ..util.misc import NestedTensor
 from .ops.functions.win_attn_func import window_attention
+from .ops.functions.layernorm_func import LayerNorm as _FusedLayerNorm
 from .position_encoding import build_position_encoding
 
 
@@ -104,6 +105,14 @@ def _window_plan(D, H, W, ws, ss):
     return src_w, inv[:-1], region_w, (Dp, Hp, Wp)
 
 
+def _lp_norm(norm_layer, dim):
+    """The norms that feed a Linear (norm1, norm2, PatchMerging.norm): the fused low-precision LayerNorm when the stock one was asked for."""
+    return _FusedLayerNorm(dim) if norm_layer is nn.LayerNorm and _FUSED_LN else norm_layer(dim)
+
+
+_FUSED_LN = os.environ.get("OCPG_FUSED_SWIN_LN", "1") != "0"
+
+
 class WindowAttention3D(nn.Module):
     def __init__(self, dim, window_size, num_heads, qkv_bias=False, qk_scale=None, attn_drop=0.0, proj_drop=0.0):
         super().__init__()
@@ -165,11 +174,11 @@ class SwinTransformerBlock3D(nn.Module):
         self.window_size, self.shift_size = tuple(window_size), tuple(shift_size)
         self.mlp_ratio, self.use_checkpoint = mlp_ratio, use_checkpoint
         assert all(0 <= s < w for s, w in zip(self.shift_size, self.window_size)), "shift_size must in 0-window_size"
-        self.norm1 = norm_layer(dim)
+        self.norm1 = _lp_norm(norm_layer, dim)
         self.attn = WindowAttention3D(dim, window_size=self.window_size, num_heads=num_heads, qkv_bias=qkv_bias,
                                       qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=drop)
         self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
-        self.norm2 = norm_layer(dim)
+        self.norm2 = _lp_norm(norm_layer, dim)
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
 
     def _plan(self, D, H, W, device):
@@ -214,7 +223,7 @@ class PatchMerging(nn.Module):
         super().__init__()
         self.dim = dim
         self.reduction = amp_cache.Linear(4 * dim, 2 * dim, bias=False)
-        self.norm = norm_layer(4 * dim)
+        self.norm = _lp_norm(norm_layer, 4 * dim)
 
     def forward(self, x):
         """[B, D, H, W, C] -> [B, D, ceil(H/2), ceil(W/2), 2C]; channel order (0,0), (1,0), (0,1), (1,1)."""

@@ -55,3 +55,31 @@ def test_mfma_window_attention(dev, dtype, bw, nw, n, h, shift):
         scale_v = ref_v.abs().max().item()
         e_mfma, e_valu = (got - ref_v).abs().max().item(), (valu - ref_v).abs().max().item()
         assert e_mfma <= 1.5 * e_valu + 6 * eps * scale_v, (name, e_mfma, e_valu, scale_v)
+
+
+@pytest.mark.parametrize("xdt,odt", [(torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16), (torch.float16, torch.float16),
+                                     (torch.float32, torch.float32)])
+@pytest.mark.parametrize("rows,c", [(1000, 96), (333, 192), (64, 384), (17, 768), (5, 1024), (2, 100), (5000, 128)])
+def test_fused_layernorm_low_precision(dev, xdt, odt, rows, c):
+    """csrc/layernorm.hip against F.layer_norm in fp32 on the same (rounded) input: y to the output dtype's rounding; dx, dgamma, dbeta
+    against autograd of the fp32 formulation."""
+    from ocpg_amd.models.ops.functions.layernorm_func import LayerNormLP
+    g = torch.Generator(device=dev).manual_seed(rows + c)
+    x = (torch.randn(rows, c, device=dev, generator=g) * 2 + 0.5).to(xdt)
+    w = torch.randn(c, device=dev, generator=g)
+    b = torch.randn(c, device=dev, generator=g)
+    go = torch.randn(rows, c, device=dev, generator=g).to(odt)
+    xa, wa, ba = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = LayerNormLP.apply(xa, wa, ba, 1e-5, odt)
+    assert y.dtype == odt
+    gx, gw, gb = torch.autograd.grad((y.float() * go.float()).sum(), (xa, wa, ba))
+    assert gx.dtype == xdt
+    xr, wr, br = x.float().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (c,), wr, br, 1e-5)
+    rx, rw, rb = torch.autograd.grad((yr * go.float()).sum(), (xr, wr, br))
+    eps_o = {torch.float32: 2e-6, torch.bfloat16: 2 ** -8, torch.float16: 2 ** -11}[odt]
+    eps_x = {torch.float32: 2e-6, torch.bfloat16: 2 ** -8, torch.float16: 2 ** -11}[xdt]
+    assert (y.float() - yr).abs().max().item() <= eps_o * yr.abs().max().item() + 1e-6
+    assert (gx.float() - rx).abs().max().item() <= eps_x * rx.abs().max().item() + 1e-5
+    assert (gw - rw).abs().max().item() <= 2e-5 * rw.abs().max().item() + 1e-4
+    assert (gb - rb).abs().max().item() <= 2e-5 * rb.abs().max().item() + 1e-4
