@@ -315,6 +315,11 @@ int ocpg_layernorm_fwd(const void* x, int x_f32, const float* gamma, const float
 int ocpg_layernorm_bwd(const void* gy, int gy_f32, const void* x, int x_f32, const float* gamma, const float* mean, const float* rstd,
                        long long rows, int C, void* dx, int dx_f32, float* part_g, float* part_b, void* stream);
 
+/* Backward of table[idx] ([T, H] -> [M, H]) for a STATIC index (the relative-position-bias lookup, models/video_swin_transformer.py:
+ * 112-114,151-153): g [M, H] fp32, order [M] int64 = argsort(idx), seg [T + 1] int64 = CSR offsets of every table row's segment in
+ * `order`; out [T, H] fully written.  Segmented sum, no atomics (autograd's index_put(accumulate): ~40 colliding atomics per address). */
+int ocpg_gather_rows_bwd(const float* g, const long long* order, const long long* seg, int T, int H, float* out, void* stream);
+
 /* Whole-step HIP-graph capture support (no reference counterpart: the reference launches eagerly).  Replaces every memset node of
  * a captured, not yet instantiated hipGraph_t by a kernel node with the same destination, value, extent and edges: with the HIP
  * runtime of ROCm 7.x a captured hipMemsetAsync writes a stale pattern from the second launch of the instantiated graph on

@@ -153,3 +153,31 @@ int ocpg_layernorm_bwd(const void* gy, int gy_f32, const void* x, int x_f32, con
 }
 
 }  // extern "C"
+
+// ---- gradient of a row gather with a STATIC index (the relative-position-bias lookup of WindowAttention3D,
+// models/video_swin_transformer.py:112-114,151-153): table [T, H] -> table[idx] [M, H].  autograd's backward is
+// index_put(accumulate): M = N^2 = 60 025 float atomics into 1 521 rows (~40 collisions per address, 161 us per block).  The
+// index is a buffer, so the rows are sorted by destination ONCE (order [M], seg [T + 1] = CSR offsets) and the backward is a
+// segmented sum: one thread per (table row, head), no atomics.
+namespace {
+
+__global__ __launch_bounds__(256) void seg_sum(const float* __restrict__ g, const long long* __restrict__ order, const long long* __restrict__ seg,
+                                               int T, int H, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= T * H) return;
+  const int t = i / H, h = i - t * H;
+  float s = 0.f;
+  for (long long p = seg[t]; p < seg[t + 1]; ++p) s += g[order[p] * H + h];
+  out[i] = s;
+}
+
+}  // namespace
+
+extern "C" int ocpg_gather_rows_bwd(const float* g, const long long* order, const long long* seg, int T, int H, float* out, void* stream) {
+  if (T <= 0 || H <= 0) return -1004;
+  if (!g || !order || !seg) return -1001;
+  if (!out) return -1006;
+  seg_sum<<<(T * H + 255) / 256, 256, 0, (hipStream_t)stream>>>(g, order, seg, T, H, out);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}

@@ -185,8 +185,8 @@ def _split_rows(m):
     if s is None:
         s = 1
         if m >= 4096:
-            want = m / 1536.0
-            cands = [d for d in range(max(2, m // 3072), min(128, m // 768) + 1) if m % d == 0]
+            want = m / _CHUNK_ROWS
+            cands = [d for d in range(max(2, int(m // (2 * _CHUNK_ROWS))), min(128, int(m // (_CHUNK_ROWS / 2))) + 1) if m % d == 0]
             if cands:
                 s = min(cands, key=lambda d: abs(d - want))
         _SPLITS[m] = s
@@ -194,6 +194,7 @@ def _split_rows(m):
 
 
 _SPLITS = {}
+_CHUNK_ROWS = float(os.environ.get("OCPG_SPLIT_ROWS", "1536"))      # rows per chunk the split aims for
 
 
 def weight_grad(gy2, x2):

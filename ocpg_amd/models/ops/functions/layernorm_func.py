@@ -56,3 +56,32 @@ class LayerNorm(torch.nn.LayerNorm):
                 and x.numel() > 0):
             return LayerNormLP.apply(x, self.weight, self.bias, self.eps, torch.get_autocast_dtype("cuda"))
         return super().forward(x)
+
+
+class StaticGather(Function):
+    """table[idx] for an index that never changes (a registered buffer): the backward is a segmented sum over rows sorted by
+    destination (csrc/layernorm.hip: seg_sum) instead of index_put(accumulate)."""
+
+    @staticmethod
+    def plan(idx, rows):
+        with torch.no_grad():
+            order = torch.argsort(idx, stable=True).contiguous()
+            seg = torch.zeros(rows + 1, dtype=torch.int64, device=idx.device)
+            seg[1:] = torch.bincount(idx, minlength=rows).cumsum(0)
+            return order, seg
+
+    @staticmethod
+    def forward(ctx, table, idx, plan):
+        ctx.plan, ctx.shape = plan, table.shape
+        return table[idx]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        order, seg = ctx.plan
+        t, h = ctx.shape
+        g2 = g.float().contiguous()
+        out = torch.empty((t, h), dtype=torch.float32, device=g.device)
+        check(lib().ocpg_gather_rows_bwd(g2.data_ptr(), order.data_ptr(), seg.data_ptr(), t, h, out.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream), "ocpg_gather_rows_bwd")
+        return out.to(g.dtype), None, None

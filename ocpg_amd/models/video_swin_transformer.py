@@ -27,7 +27,7 @@ from . import amp_cache
 
 from ..util.misc import NestedTensor
 from .ops.functions.win_attn_func import window_attention
-from .ops.functions.layernorm_func import LayerNorm as _FusedLayerNorm
+from .ops.functions.layernorm_func import LayerNorm as _FusedLayerNorm, StaticGather
 from .position_encoding import build_position_encoding
 
 
@@ -137,7 +137,13 @@ class WindowAttention3D(nn.Module):
     def relative_position_bias(self, n):
         """[heads, N, N]; the index table is sliced [:N, :N] for a clamped window exactly as the reference does."""
         idx = self.relative_position_index[:n, :n].reshape(-1)
-        return self.relative_position_bias_table[idx].view(n, n, -1).permute(2, 0, 1)
+        table = self.relative_position_bias_table
+        if table.is_cuda and table.dtype == torch.float32 and table.requires_grad and torch.is_grad_enabled():
+            plan = self.__dict__.get("_gather_plan")                     # the index is a buffer: sorted by destination once per N
+            if plan is None or plan[0] != (n, table.device):
+                plan = self.__dict__["_gather_plan"] = ((n, table.device), StaticGather.plan(idx, table.shape[0]))
+            return StaticGather.apply(table, idx, plan[1]).view(n, n, -1).permute(2, 0, 1)
+        return table[idx].view(n, n, -1).permute(2, 0, 1)
 
     def forward(self, x, mask=None, region=None):
         """x [num_windows*B, N, C]; mask [num_windows, N, N] additive (0 / -100) or None; region [num_windows, N] int32 =
