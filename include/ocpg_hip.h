@@ -320,6 +320,12 @@ int ocpg_layernorm_bwd(const void* gy, int gy_f32, const void* x, int x_f32, con
  * `order`; out [T, H] fully written.  Segmented sum, no atomics (autograd's index_put(accumulate): ~40 colliding atomics per address). */
 int ocpg_gather_rows_bwd(const float* g, const long long* order, const long long* seg, int T, int H, float* out, void* stream);
 
+/* Row gather with padding slots: out [B, M, row] = idx[j] in [0, S) ? x [B, S, row][:, idx[j]] : 0; rows are row_bytes bytes (multiple of
+ * 16, any dtype).  Video-Swin's pad + cyclic shift + window partition and its reverse (models/video_swin_transformer.py:171-199) are
+ * two such gathers that are each other's backward. */
+int ocpg_gather_rows_pad(const void* x, const long long* idx, long long B, long long S, long long M, long long row_bytes, void* out,
+                         void* stream);
+
 /* Whole-step HIP-graph capture support (no reference counterpart: the reference launches eagerly).  Replaces every memset node of
  * a captured, not yet instantiated hipGraph_t by a kernel node with the same destination, value, extent and edges: with the HIP
  * runtime of ROCm 7.x a captured hipMemsetAsync writes a stale pattern from the second launch of the instantiated graph on

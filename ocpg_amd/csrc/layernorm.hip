@@ -181,3 +181,36 @@ extern "C" int ocpg_gather_rows_bwd(const float* g, const long long* order, cons
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
+
+// ---- row gather with padding slots: out[b, j, :] = idx[j] < S ? x[b, idx[j], :] : 0, rows moved as 16-byte segments (any dtype).
+// Video-Swin's pad + cyclic shift + window partition (and its reverse) is one such gather (models/video_swin_transformer.py:
+// 171-199 does pad, roll, view/permute, and the mirror image); because every token sits in exactly one window slot, the backward
+// of the partition gather IS the reverse gather and vice versa -- no index_add atomics, no appended zero row.
+namespace {
+
+__global__ __launch_bounds__(256) void gather_rows_pad(const uint4* __restrict__ x, const long long* __restrict__ idx, long long S, long long M,
+                                                       int segs, uint4* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // over M * segs of one batch element
+  if (i >= M * segs) return;
+  const long long j = i / segs;
+  const int sg = (int)(i - j * segs);
+  const long long b = blockIdx.y, src = idx[j];
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if (src >= 0 && src < S) v = x[(b * S + src) * segs + sg];
+  out[(b * M + j) * segs + sg] = v;
+}
+
+}  // namespace
+
+extern "C" int ocpg_gather_rows_pad(const void* x, const long long* idx, long long B, long long S, long long M, long long row_bytes, void* out,
+                                    void* stream) {
+  if (B < 0 || S < 0 || M < 0 || row_bytes <= 0 || row_bytes % 16 != 0 || B > 65535) return -1005;
+  if (B == 0 || M == 0) return 0;
+  if (!x || !idx) return -1001;
+  if (!out) return -1007;
+  const int segs = (int)(row_bytes / 16);
+  const dim3 grid((unsigned)((M * segs + 255) / 256), (unsigned)B);
+  gather_rows_pad<<<grid, 256, 0, (hipStream_t)stream>>>((const uint4*)x, idx, S, M, segs, (uint4*)out);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}

@@ -85,3 +85,34 @@ class StaticGather(Function):
         check(lib().ocpg_gather_rows_bwd(g2.data_ptr(), order.data_ptr(), seg.data_ptr(), t, h, out.data_ptr(),
                                          torch.cuda.current_stream().cuda_stream), "ocpg_gather_rows_bwd")
         return out.to(g.dtype), None, None
+
+
+class PermuteGather(Function):
+    """out[b, j] = x[b, fwd_idx[j]] (a slot whose index is outside [0, S) reads zeros); `bwd_idx` [S] is the inverse map (for every source
+    row the slot that holds it, or -1): the backward is the same kernel with the roles swapped."""
+
+    @staticmethod
+    def forward(ctx, x, fwd_idx, bwd_idx):
+        x = x.contiguous()
+        b, s, c = x.shape
+        m = fwd_idx.shape[0]
+        out = torch.empty((b, m, c), dtype=x.dtype, device=x.device)
+        check(lib().ocpg_gather_rows_pad(x.data_ptr(), fwd_idx.data_ptr(), b, s, m, c * x.element_size(), out.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream), "ocpg_gather_rows_pad")
+        ctx.idx, ctx.s = (fwd_idx, bwd_idx), s
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        fwd_idx, bwd_idx = ctx.idx
+        g = g.contiguous()
+        b, m, c = g.shape
+        gx = torch.empty((b, ctx.s, c), dtype=g.dtype, device=g.device)
+        check(lib().ocpg_gather_rows_pad(g.data_ptr(), bwd_idx.data_ptr(), b, m, ctx.s, c * g.element_size(), gx.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream), "ocpg_gather_rows_pad")
+        return gx, None, None
+
+
+def permute_gather_ok(x):
+    return x.is_cuda and x.dim() == 3 and (x.shape[-1] * x.element_size()) % 16 == 0

@@ -27,7 +27,7 @@ from . import amp_cache
 
 from ..util.misc import NestedTensor
 from .ops.functions.win_attn_func import window_attention
-from .ops.functions.layernorm_func import LayerNorm as _FusedLayerNorm, StaticGather
+from .ops.functions.layernorm_func import LayerNorm as _FusedLayerNorm, PermuteGather, StaticGather, permute_gather_ok
 from .position_encoding import build_position_encoding
 
 
@@ -103,6 +103,16 @@ def _window_plan(D, H, W, ws, ss):
     flat = src_w.reshape(-1)
     inv[flat] = np.arange(flat.size)
     return src_w, inv[:-1], region_w, (Dp, Hp, Wp)
+
+
+def gather_in_inv(gather_in, S, owner, key):
+    """Backward map of the reverse gather: for every window SLOT the token it holds, or -1 for a padded slot = gather_in with the
+    out-of-range marker replaced (cached on the block)."""
+    cache = owner.__dict__.setdefault("_gather_inv", {})
+    k = (key, gather_in.device)
+    if k not in cache:
+        cache[k] = torch.where(gather_in < S, gather_in, torch.full_like(gather_in, -1))
+    return cache[k]
 
 
 def _lp_norm(norm_layer, dim):
@@ -207,6 +217,14 @@ class SwinTransformerBlock3D(nn.Module):
         B, D, H, W, C = x.shape
         gather_in, gather_out, mask, region, (nw, n) = self._plan(D, H, W, x.device)
         x = self.norm1(x).view(B, D * H * W, C)
+        if permute_gather_ok(x):
+            # pad + roll + partition as ONE gather kernel whose backward is the reverse gather (every token sits in exactly one slot:
+            # no index_add atomics, no appended zero row); gather_in marks padded slots with D*H*W (out of range -> zeros)
+            windows = PermuteGather.apply(x, gather_in, gather_out).view(B * nw, n, C)
+            out = self.attn(windows, mask=mask, region=region).view(B, nw * n, C)
+            if permute_gather_ok(out):
+                return PermuteGather.apply(out, gather_out, gather_in_inv(gather_in, D * H * W, self, (D, H, W))).view(B, D, H, W, C)
+            return out.index_select(1, gather_out).view(B, D, H, W, C)
         x = torch.cat([x, x.new_zeros(B, 1, C)], dim=1)                                   # the zero row read by padded slots
         windows = x.index_select(1, gather_in).view(B * nw, n, C)                         # pad + roll + partition: one gather
         out = self.attn(windows, mask=mask, region=region).view(B, nw * n, C)
