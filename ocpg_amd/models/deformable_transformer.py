@@ -195,6 +195,29 @@ class DeformableTransformerDecoder(nn.Module):
         return out, reference_points, samples_keep
 
 
+class _LevelPos(torch.autograd.Function):
+    """cat_l(pos_l) + level_embed[l] broadcast over the tokens of level l (deformable_transformer.py:158-159); pos is a constant."""
+
+    @staticmethod
+    def forward(ctx, pos_cat, level_embed, sizes):
+        ctx.sizes = sizes
+        out = pos_cat.clone()
+        start = 0
+        for l, n in enumerate(sizes):
+            out[:, start:start + n] += level_embed[l]
+            start += n
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        gs = g.sum(0)                                    # [S, C]: one pass over the frames
+        parts, start = [], 0
+        for n in ctx.sizes:
+            parts.append(gs[start:start + n].sum(0))
+            start += n
+        return None, torch.stack(parts).to(g.dtype), None
+
+
 class DeformableTransformer(nn.Module):
     def __init__(self, d_model=256, nhead=8, num_encoder_layers=6, num_decoder_layers=6, dim_feedforward=1024,
                  dropout=0.1, activation="relu", return_intermediate_dec=False, num_feature_levels=4,
@@ -256,7 +279,13 @@ class DeformableTransformer(nn.Module):
         # and its backward in every MSDeformAttn call (2 x 52 MB passes each at config #2)
         unpadded = all(fully_valid(mask_key(m)) for m in masks)
         mask = None if unpadded else torch.cat([m.flatten(1) for m in masks], 1)
-        pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[l].view(1, 1, -1) for l, p in enumerate(pos_embeds)], 1)
+        if all(not p.requires_grad for p in pos_embeds):
+            # position encodings are constants: one add forward, and backward ONE sum over the frames + L small segment sums for
+            # level_embed (the per-level broadcast adds cost 4 x (80 us reduction + zeros + copy + add) at config #2)
+            pos = _LevelPos.apply(torch.cat([p.flatten(2).transpose(1, 2) for p in pos_embeds], 1), self.level_embed,
+                                  tuple(h * w for h, w in shapes_host))
+        else:
+            pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[l].view(1, 1, -1) for l, p in enumerate(pos_embeds)], 1)
         spatial_shapes, level_start_index = self._level_geometry(tuple(shapes_host), dev)
         keys = tuple(mask_key(m) for m in masks)
         keys = None if any(k is None for k in keys) else keys
