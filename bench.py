@@ -147,6 +147,9 @@ class GraphStep:
         self.fence = os.environ.get("OCPG_GRAPH_FENCE") == "1"       # diagnostic: host syncs around every replay
         first = make_samples()
         self.x, self.mask = first.tensors.clone(), first.mask.clone()
+        # the collate step's host-side knowledge of every frame's valid extent (util.misc.tag_rect_mask) must survive the copies:
+        # without it the captured step takes the uncached path (position encodings, level masks, 18 masked_fill passes per step)
+        self.mask_key = getattr(first.mask, "_ocpg_key", None)
         self.num_boxes = criterion.global_num_boxes(targets, self.x.device).clone()
         criterion.iter_device = torch.zeros((), device=self.x.device)       # the criterion's call counter, device-resident
         self.calls_per_fwd = args.dec_layers
@@ -163,7 +166,7 @@ class GraphStep:
         with torch.cuda.stream(side):
             for _ in range(3):                      # warm-up on the capture stream: MIOpen find, FFT plans, workspaces
                 optimizer.zero_grad(set_to_none=True)
-                forward_backward(model, criterion, NestedTensor(self.x.clone(), self.mask.clone()), text, targets, amp_dtype, self.num_boxes)
+                forward_backward(model, criterion, NestedTensor(self.x.clone(), self._mask()), text, targets, amp_dtype, self.num_boxes)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         optimizer.zero_grad(set_to_none=True)
@@ -175,7 +178,7 @@ class GraphStep:
         # (a hipMalloc inside the capture would invalidate it)
         # N > 1: RCCL's watchdog thread may poll events while we capture; only THIS thread's unsafe calls should invalidate the capture
         with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local" if world > 1 else "global"):
-            self.loss = forward_backward(model, criterion, NestedTensor(self.x.clone(), self.mask.clone()), text, targets, amp_dtype,
+            self.loss = forward_backward(model, criterion, NestedTensor(self.x.clone(), self._mask()), text, targets, amp_dtype,
                                          self.num_boxes, keep=self.static)
         # memset nodes (torch's reduction semaphores) replay with a corrupted pattern on this ROCm: swap them for kernel nodes
         import ctypes
@@ -196,6 +199,12 @@ class GraphStep:
         assert all(g is not None for g in self.grads), "a trainable parameter received no gradient"
         self.flat = None
 
+    def _mask(self):
+        m = self.mask.clone()
+        if self.mask_key is not None:
+            m._ocpg_key = self.mask_key
+        return m
+
     def check(self, eager_loss, rtol=0.25):
         """One replay (no optimizer step) against the eager loss of the warm-up steps: finite, same ballpark (dropout
         masks differ), every gradient finite."""
@@ -208,6 +217,7 @@ class GraphStep:
 
     def __call__(self):
         s = self.make_samples()
+        assert getattr(s.mask, "_ocpg_key", None) == self.mask_key, "the captured step assumes the valid extents it was captured with"
         self.x.copy_(s.tensors), self.mask.copy_(s.mask)
         self.num_boxes.copy_(self.criterion.global_num_boxes(self.targets, self.x.device))
         if self.fence:
