@@ -145,6 +145,20 @@ class GraphStep:
         self.model, self.criterion, self.optimizer, self.args, self.world = model, criterion, optimizer, args, world
         self.make_samples, self.targets = make_samples, targets
         self.fence = os.environ.get("OCPG_GRAPH_FENCE") == "1"       # diagnostic: host syncs around every replay
+        # fp16: the reference's GradScaler path (engine.py:98-104).  The scale is a device scalar, so `scale(loss).backward()` is
+        # captured; unscale_ / clip / step (with its inf check) / update stay eager after the replay
+        self.scaler = torch.amp.GradScaler("cuda") if amp_dtype == torch.float16 else None
+        # captions (config #5): tokenisation uploads host tensors, which a capture cannot contain.  The FROZEN text backbone therefore
+        # runs eagerly before every replay (same work per step as the eager path, `freeze_text_encoder` as in every launch script) and
+        # hands its outputs to the captured step through static buffers; the trainable resizers stay inside the graph.
+        self.captions, self.amp_dtype = None, amp_dtype
+        if isinstance(text, (list, tuple)) and text and isinstance(text[0], str):
+            if not getattr(model.text_encoder, "freeze_text_encoder", False):
+                raise RuntimeError("captured step needs a frozen text encoder")
+            from ocpg_amd.models.text_encoder.text_encoder import PrecomputedText
+            self.captions = text
+            text = PrecomputedText(*[t.clone() for t in self._encode_text()])
+        self.text = text
         first = make_samples()
         self.x, self.mask = first.tensors.clone(), first.mask.clone()
         # the collate step's host-side knowledge of every frame's valid extent (util.misc.tag_rect_mask) must survive the copies:
@@ -166,7 +180,8 @@ class GraphStep:
         with torch.cuda.stream(side):
             for _ in range(3):                      # warm-up on the capture stream: MIOpen find, FFT plans, workspaces
                 optimizer.zero_grad(set_to_none=True)
-                forward_backward(model, criterion, NestedTensor(self.x.clone(), self._mask()), text, targets, amp_dtype, self.num_boxes)
+                forward_backward(model, criterion, NestedTensor(self.x.clone(), self._mask()), text, targets, amp_dtype, self.num_boxes,
+                                 scaler=self.scaler)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         optimizer.zero_grad(set_to_none=True)
@@ -179,7 +194,7 @@ class GraphStep:
         # N > 1: RCCL's watchdog thread may poll events while we capture; only THIS thread's unsafe calls should invalidate the capture
         with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local" if world > 1 else "global"):
             self.loss = forward_backward(model, criterion, NestedTensor(self.x.clone(), self._mask()), text, targets, amp_dtype,
-                                         self.num_boxes, keep=self.static)
+                                         self.num_boxes, keep=self.static, scaler=self.scaler)
         # memset nodes (torch's reduction semaphores) replay with a corrupted pattern on this ROCm: swap them for kernel nodes
         import ctypes
         from ocpg_amd import _lib
@@ -199,6 +214,11 @@ class GraphStep:
         assert all(g is not None for g in self.grads), "a trainable parameter received no gradient"
         self.flat = None
 
+    def _encode_text(self):
+        dev = next(self.model.parameters()).device
+        with torch.no_grad(), torch.autocast(device_type=dev.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
+            return self.model.text_encoder(self.captions, dev)
+
     def _mask(self):
         m = self.mask.clone()
         if self.mask_key is not None:
@@ -211,7 +231,9 @@ class GraphStep:
         self.graph.replay()
         torch.cuda.synchronize()
         loss = float(self.loss)
-        ok = loss == loss and abs(loss - eager_loss) <= rtol * abs(eager_loss) and all(bool(torch.isfinite(g).all()) for g in self.grads)
+        # (fp16: a replay at the initial loss scale may overflow -- that is the scaler's business, not a capture failure)
+        ok = loss == loss and abs(loss - eager_loss) <= rtol * abs(eager_loss) and (self.scaler is not None or
+                                                                                  all(bool(torch.isfinite(g).all()) for g in self.grads))
         if not ok:
             raise RuntimeError(f"graph replay disagrees with eager: {loss} vs {eager_loss}")
 
@@ -220,6 +242,9 @@ class GraphStep:
         assert getattr(s.mask, "_ocpg_key", None) == self.mask_key, "the captured step assumes the valid extents it was captured with"
         self.x.copy_(s.tensors), self.mask.copy_(s.mask)
         self.num_boxes.copy_(self.criterion.global_num_boxes(self.targets, self.x.device))
+        if self.captions is not None:
+            for dst, src in zip(self.text, self._encode_text()):
+                dst.copy_(src)
         if self.fence:
             torch.cuda.synchronize()
         self.graph.replay()
@@ -231,9 +256,15 @@ class GraphStep:
             dist.all_reduce(flat)
             flat.div_(self.world)
             torch._foreach_copy_(self.grads, list(torch._utils._unflatten_dense_tensors(flat, self.grads)))
+        if self.scaler is not None:
+            self.scaler.unscale_(self.optimizer)
         if self.args.clip_max_norm > 0:
             torch.nn.utils.clip_grad_norm_(self.params, self.args.clip_max_norm, error_if_nonfinite=False, foreach=True)
-        self.optimizer.step()
+        if self.scaler is not None:
+            self.scaler.step(self.optimizer)
+            self.scaler.update()
+        else:
+            self.optimizer.step()
         return self.loss
 
 
@@ -430,7 +461,7 @@ def main():
     amp_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}[a.dtype]
     make_samples, text, targets = synthetic_batch(a.clips_per_gpu, device, seed=42 + rank, roberta=a.text == "roberta")
     step, mode = None, "eager"
-    if not a.eager and amp_dtype != torch.float16:       # fp16 needs the GradScaler's host-side skip logic: eager
+    if not a.eager:
         snapshot = {k: v.clone() for k, v in model.state_dict().items()}
 
         def back_to_eager():
@@ -464,7 +495,7 @@ def main():
                 ok, step = 0, None
         if ok:
             for _ in range(3):      # the round-1 instability showed after optimizer steps: exercise them before the timed region
-                if not bool(torch.isfinite(step())):
+                if not bool(torch.isfinite(step())) and amp_dtype != torch.float16:       # fp16: overflowed steps are the scaler's to skip
                     raise RuntimeError("graph replay turned non-finite after an optimizer step")
             mode = "hipgraph(fwd+criterion+bwd)"
         else:
