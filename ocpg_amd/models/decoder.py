@@ -9,6 +9,9 @@ from torch import nn
 
 from . import amp_cache
 from .amp_cache import lookup
+from .resample import bilinear_resize
+
+MATMUL_BILINEAR = True       # A/B switch: bilinear resampling as two matrix products (no atomics backward)
 
 
 class MSO(nn.Module):
@@ -58,7 +61,8 @@ def _mso_forward_multi(self, pred_masks_list, image_features, stacked=False):
     shared8 = F.conv2d(F.relu(_conv_input(f8, dt)), w8[:, c:], lookup(self.conv1_1div8.bias), padding=1)
     y = F.conv2d(F.relu(pm), w8[:, :c], None, padding=1) + shared8.repeat(n, 1, 1, 1)
     pm = pm + self.conv2_1div8(F.relu(y))
-    pm = F.interpolate(pm, size=f4.shape[-2:], mode="bilinear", align_corners=False)
+    pm = (bilinear_resize(pm, tuple(f4.shape[-2:]), False) if pm.is_cuda and MATMUL_BILINEAR
+          else F.interpolate(pm, size=f4.shape[-2:], mode="bilinear", align_corners=False))
     assert pm.shape[-1] == f4.shape[-1], "Second size wrong."
     w4 = lookup(self.conv1_1div4.weight)
     shared4 = F.conv2d(F.relu(_conv_input(f4, dt)), w4[:, c:], lookup(self.conv1_1div4.bias), padding=1)

@@ -32,7 +32,9 @@ from .modules import LFMResizeAdaptive
 from .ops.functions.dynmask_func import dynamic_mask
 from .position_encoding import PositionEmbeddingSine1D
 from .postprocessors import build_postprocessors
-from .resample import bicubic_resize
+from .resample import bicubic_resize, bilinear_resize
+
+MATMUL_BILINEAR = True       # A/B switch: bilinear resampling as two matrix products (no atomics backward)
 from .segmentation import VisionLanguageFusionModule
 from .text_encoder.text_encoder import FeatureResizer, PrecomputedText, TextEncoder
 
@@ -296,11 +298,14 @@ class OCPG(nn.Module):
                     out["aux_outputs"] = self._set_aux_loss(outputs_class, outputs_coord, seg_masks_shuffled)
                     out["aux_matcher_index"] = [self.matcher.as_indices(src_all[i]) for i in range(nl - 1)]
             if self.aux_loss:
-                ls_feat = F.interpolate(self.ls_feat_viz(memory_fusion), scale_factor=4, mode="bilinear", align_corners=True)
+                lsf = self.ls_feat_viz(memory_fusion)
+                ls_feat = (bilinear_resize(lsf, (4 * lsf.shape[-2], 4 * lsf.shape[-1]), True) if lsf.is_cuda and MATMUL_BILINEAR
+                           else F.interpolate(lsf, scale_factor=4, mode="bilinear", align_corners=True))
                 ls_feat = ls_feat.unflatten(0, (b, t))                              # [b, t, 8, 4h, 4w]
                 txt = self.ls_text_proj(text_sentence)[:, None, :, None, None]
                 sim = (ls_feat * txt).sum(dim=2) / ((F.normalize(ls_feat, dim=2) * F.normalize(txt, dim=2)).sum(dim=2) + 1e-5)
-                img = F.interpolate(samples.tensors, ls_feat.shape[-2:], mode="bilinear", align_corners=True).unflatten(0, (b, t))
+                img = (bilinear_resize(samples.tensors, tuple(ls_feat.shape[-2:]), True) if lsf.is_cuda and MATMUL_BILINEAR
+                       else F.interpolate(samples.tensors, ls_feat.shape[-2:], mode="bilinear", align_corners=True)).unflatten(0, (b, t))
                 ls_features = torch.cat([img, ls_feat, sim.unsqueeze(2)], dim=2)    # [b, t, 12, 4h, 4w]  (same for every query)
 
                 # the matched query of every layer: one gather over [l, b, t, q, ...]

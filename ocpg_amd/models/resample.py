@@ -44,3 +44,37 @@ def bicubic_resize(x, size):
     wy = bicubic_matrix(h, H, x.device).to(x.dtype)
     wx = bicubic_matrix(w, W, x.device).to(x.dtype)
     return torch.matmul(wy, torch.matmul(x, wx.t()))
+
+
+def bilinear_matrix(n_in, n_out, align_corners, device):
+    """[n_out, n_in] fp32 matrix of 1-D bilinear resampling with ATen's source-index rules (upsample_bilinear2d: align_corners=True
+    -> dst * (in - 1) / (out - 1); False -> max((dst + 0.5) * in / out - 0.5, 0); second tap clamped to the last index)."""
+    key = ("bilinear", n_in, n_out, bool(align_corners), str(device))
+    if key not in _CACHE:
+        dst = torch.arange(n_out, dtype=torch.float32)
+        if align_corners:
+            src = dst * ((n_in - 1) / (n_out - 1)) if n_out > 1 else torch.zeros_like(dst)
+        else:
+            src = ((dst + 0.5) * (n_in / n_out) - 0.5).clamp(min=0)
+        i0 = torch.floor(src).clamp(max=n_in - 1)
+        lam = src - i0
+        i0 = i0.long()
+        i1 = (i0 + 1).clamp(max=n_in - 1)
+        m = torch.zeros(n_out, n_in)
+        m.scatter_add_(1, i0[:, None], (1 - lam)[:, None])
+        m.scatter_add_(1, i1[:, None], lam[:, None])
+        _CACHE[key] = m.to(device)
+    return _CACHE[key]
+
+
+def bilinear_resize(x, size, align_corners):
+    """F.interpolate(x, size, mode="bilinear", align_corners=...) for [N, C, h, w] as two matrix products in fp32 (ATen's backward,
+    upsample_bilinear2d_backward, scatters with float atomics: 175 us per call at the 192 x 320 level-set maps); the result is
+    returned in x's dtype, as F.interpolate does."""
+    h, w = x.shape[-2:]
+    H, W = size
+    wy = bilinear_matrix(h, H, align_corners, x.device)
+    wx = bilinear_matrix(w, W, align_corners, x.device)
+    with torch.autocast(device_type=x.device.type, enabled=False):
+        y = torch.matmul(wy, torch.matmul(x.float(), wx.t()))
+    return y.to(x.dtype)

@@ -1063,3 +1063,23 @@ def test_full_size_gradients_vs_oracle(dev):
           f"grad norm {sq_a ** 0.5:.5g} vs {sq_b ** 0.5:.5g}")
     assert abs(sq_a ** 0.5 - sq_b ** 0.5) <= 1e-3 * sq_b ** 0.5
     assert rel[n // 2][0] <= 5e-4 and rel[int(0.97 * n)][0] <= 1e-2, rel[-5:]
+
+
+@pytest.mark.parametrize("align", [True, False])
+@pytest.mark.parametrize("shape,size", [((3, 8, 48, 80), (192, 320)), ((2, 16, 48, 80), (96, 160)), ((2, 3, 37, 53), (41, 97)), ((1, 2, 5, 7), (5, 7)),
+                                        ((1, 1, 1, 4), (3, 9))])
+def test_bilinear_resize_as_matmul(dev, align, shape, size):
+    """models/resample.bilinear_resize == F.interpolate(mode="bilinear") for both align_corners conventions, up- and down-sampling,
+    degenerate sizes; value and input gradient."""
+    from ocpg_amd.models.resample import bilinear_resize
+    g = torch.Generator(device=dev).manual_seed(sum(shape) + size[0])
+    x = torch.randn(*shape, device=dev, generator=g)
+    go = torch.randn(*shape[:2], *size, device=dev, generator=g)
+    a = x.clone().requires_grad_(True)
+    b = x.clone().requires_grad_(True)
+    ya = bilinear_resize(a, size, align)
+    yb = torch.nn.functional.interpolate(b, size=size, mode="bilinear", align_corners=align)
+    assert (ya - yb).abs().max().item() <= 5e-6 * yb.abs().max().item() + 2e-6          # fp32 GEMM summation order + weight rounding
+    ga, = torch.autograd.grad((ya * go).sum(), a)
+    gb, = torch.autograd.grad((yb * go).sum(), b)
+    assert (ga - gb).abs().max().item() <= 2e-5 * gb.abs().max().item() + 1e-6
