@@ -32,7 +32,7 @@ from .modules import LFMResizeAdaptive
 from .ops.functions.dynmask_func import dynamic_mask
 from .position_encoding import PositionEmbeddingSine1D
 from .postprocessors import build_postprocessors
-from .resample import bicubic_resize, bilinear_resize
+from .resample import bicubic_resize, bilinear_resize, nearest_upsample
 
 MATMUL_BILINEAR = True       # A/B switch: bilinear resampling as two matrix products (no atomics backward)
 from .segmentation import VisionLanguageFusionModule
@@ -313,7 +313,7 @@ class OCPG(nn.Module):
                 gi = src_all[:, :, None, None, None, None, None].expand(nl, b, t, 1, 16, tar[0], tar[1])
                 picked = torch.gather(seg, 3, gi).squeeze(3).flatten(1, 2)          # [l, (b t), 16, h, w]
                 refined = self.mask_refine.forward_multi(list(picked.unbind(0)), features[:2], stacked=True)   # [l*(b t), 1, 2h, 2w]
-                refined = F.interpolate(refined, scale_factor=4).squeeze(1)
+                refined = nearest_upsample(refined, 4).squeeze(1)
                 refined = refined.view(nl, b, t, *refined.shape[-2:])
                 gl = src_all[:, :, None, None, None, None].expand(nl, b, t, 1, 4 * tar[0], 4 * tar[1])
                 low = torch.gather(shuffled, 3, gl).squeeze(3)                      # [l, b, t, 4h, 4w]

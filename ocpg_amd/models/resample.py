@@ -78,3 +78,22 @@ def bilinear_resize(x, size, align_corners):
     with torch.autocast(device_type=x.device.type, enabled=False):
         y = torch.matmul(wy, torch.matmul(x.float(), wx.t()))
     return y.to(x.dtype)
+
+
+class _NearestUp(torch.autograd.Function):
+    """F.interpolate(x, scale_factor=k) (nearest, integer k): every pixel becomes a k x k block, so the backward is a k x k block sum
+    (one pooling kernel; ATen's upsample_nearest2d_backward took 120 us on the [40, 1, 384, 640] refined masks)."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        ctx.k = k
+        return torch.nn.functional.interpolate(x, scale_factor=k)
+
+    @staticmethod
+    def backward(ctx, g):
+        k = ctx.k
+        return torch.nn.functional.avg_pool2d(g, k) * float(k * k), None
+
+
+def nearest_upsample(x, k):
+    return _NearestUp.apply(x, int(k))
