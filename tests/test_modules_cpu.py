@@ -98,3 +98,46 @@ def test_row_split_and_layout_helpers():
     full = ("rect", 64, 96, ((64, 96),) * 4)
     assert misc.fully_valid(full) and misc.fully_valid(("resized", full, (8, 12)))
     assert not misc.fully_valid(("rect", 64, 96, ((64, 96), (60, 96)))) and not misc.fully_valid(None)
+
+
+def test_resampling_helpers_match_interpolate():
+    """models/resample.py (pure tensor programs, device-independent): bilinear as two matrix products for both align_corners
+    conventions, nearest xk with a block-sum backward -- values and gradients against F.interpolate."""
+    import torch.nn.functional as F
+    from ocpg_amd.models.resample import bilinear_resize, nearest_upsample
+    torch.manual_seed(0)
+    for align in (True, False):
+        for shape, size in (((2, 3, 12, 20), (48, 80)), ((1, 2, 7, 5), (4, 9)), ((1, 1, 1, 3), (2, 5))):
+            x = torch.randn(*shape, dtype=torch.float64).float()
+            a, b = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+            ya, yb = bilinear_resize(a, size, align), F.interpolate(b, size=size, mode="bilinear", align_corners=align)
+            assert (ya - yb).abs().max().item() <= 5e-6
+            go = torch.randn_like(yb)
+            ga, = torch.autograd.grad((ya * go).sum(), a)
+            gb, = torch.autograd.grad((yb * go).sum(), b)
+            assert (ga - gb).abs().max().item() <= 2e-5
+    x = torch.randn(3, 1, 6, 10)
+    a, b = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = nearest_upsample(a, 4), F.interpolate(b, scale_factor=4)
+    assert torch.equal(ya, yb)
+    go = torch.randn_like(yb)
+    ga, = torch.autograd.grad((ya * go).sum(), a)
+    gb, = torch.autograd.grad((yb * go).sum(), b)
+    assert (ga - gb).abs().max().item() <= 1e-5
+
+
+def test_level_embedding_function_matches_broadcast_adds():
+    """deformable_transformer._LevelPos == cat_l(pos_l + level_embed[l]) (deformable_transformer.py:158-159) incl. the gradient."""
+    from ocpg_amd.models.deformable_transformer import _LevelPos
+    torch.manual_seed(1)
+    sizes = (12, 6, 2, 1)
+    pos = [torch.randn(3, n, 8) for n in sizes]
+    le = torch.randn(4, 8, requires_grad=True)
+    le2 = le.detach().clone().requires_grad_(True)
+    out = _LevelPos.apply(torch.cat(pos, 1), le, sizes)
+    ref = torch.cat([p + le2[l].view(1, 1, -1) for l, p in enumerate(pos)], 1)
+    assert torch.allclose(out, ref, atol=1e-6)
+    go = torch.randn_like(ref)
+    g1, = torch.autograd.grad((out * go).sum(), le)
+    g2, = torch.autograd.grad((ref * go).sum(), le2)
+    assert torch.allclose(g1, g2, atol=1e-5)
