@@ -315,6 +315,20 @@ int ocpg_layernorm_fwd(const void* x, int x_f32, const float* gamma, const float
 int ocpg_layernorm_bwd(const void* gy, int gy_f32, const void* x, int x_f32, const float* gamma, const float* mean, const float* rstd,
                        long long rows, int C, void* dx, int dx_f32, float* part_g, float* part_b, void* stream);
 
+/* nn.GroupNorm behind the input projections (models/ocpg.py:108-119: Conv2d -> GroupNorm(32, hidden) per level) between the layouts
+ * its neighbours use (csrc/groupnorm.hip): x [N, HW, C] channels-last with storage code x_dtype (1 fp32, 0 bf16, 2 fp16) as the projection
+ * GEMM writes it, y [N, C, HW] fp32 planes as the LFM's FFTs read them; gamma / beta fp32 [C]; mean / rstd [N, G] fp32 kept for the backward.
+ *   bwd: gy [N, C, HW] fp32 -> dx [N, HW, C] in x's dtype; part [N, 2, C] fp32 = per-frame partial sums of dgamma ([:, 0]) and dbeta ([:, 1]),
+ *        summed over N by the caller.
+ * Groups of exactly 8 channels (C == 8 G, the reference's 256 / 32), else -2000.  Large maps (C == 256, HW >= 1500) are tiled over pixels
+ * and need scratch: work = ocpg_groupnorm_cl_work(N, HW, C, G) floats (0: not needed, work may be NULL); the forward's and the backward's
+ * scratch are independent (nothing is carried between the two calls through it). */
+long long ocpg_groupnorm_cl_work(long long N, int HW, int C, int G);
+int ocpg_groupnorm_cl_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, long long N, int HW, int C, int G, float eps,
+                          float* y, float* mean, float* rstd, float* work, void* stream);
+int ocpg_groupnorm_cl_bwd(const float* gy, const void* x, int x_dtype, const float* gamma, const float* mean, const float* rstd, long long N,
+                          int HW, int C, int G, void* dx, float* part, float* work, void* stream);
+
 /* Backward of table[idx] ([T, H] -> [M, H]) for a STATIC index (the relative-position-bias lookup, models/video_swin_transformer.py:
  * 112-114,151-153): g [M, H] fp32, order [M] int64 = argsort(idx), seg [T + 1] int64 = CSR offsets of every table row's segment in
  * `order`; out [T, H] fully written.  Segmented sum, no atomics (autograd's index_put(accumulate): ~40 colliding atomics per address). */

@@ -38,6 +38,9 @@ SIGNATURES = {
     "ocpg_small_linear_fwd": [_vp, _int, _vp, _vp, _int, _int, _int, _int, _vp, _vp],
     "ocpg_small_linear_bwd": [_vp, _int, _vp, _int, _vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp],
     "ocpg_layernorm_blocks": [ctypes.c_longlong],
+    "ocpg_groupnorm_cl_work": [ctypes.c_longlong, _int, _int, _int],
+    "ocpg_groupnorm_cl_fwd": [_vp, _int, _vp, _vp, ctypes.c_longlong, _int, _int, _int, ctypes.c_float, _vp, _vp, _vp, _vp, _vp],
+    "ocpg_groupnorm_cl_bwd": [_vp, _vp, _int, _vp, _vp, _vp, ctypes.c_longlong, _int, _int, _int, _vp, _vp, _vp, _vp],
     "ocpg_layernorm_fwd": [_vp, _int, _vp, _vp, ctypes.c_longlong, _int, ctypes.c_float, _vp, _int, _vp, _vp, _vp],
     "ocpg_layernorm_bwd": [_vp, _int, _vp, _int, _vp, _vp, _vp, ctypes.c_longlong, _int, _vp, _int, _vp, _vp, _vp],
     "ocpg_gather_rows_bwd": [_vp, _vp, _vp, _int, _int, _vp, _vp],
@@ -82,7 +85,7 @@ SIGNATURES = {
 
 # ---- optional live kernel timing (bench.py): HIP events on the launch stream around every library call ----------
 _TIMING = {"on": False, "events": []}
-_UNTIMED = ("ocpg_gemm_plans", "ocpg_bias_relu_dropout_bwd_slots", "ocpg_dropout_add_ln_bwd_slots")
+_UNTIMED = ("ocpg_gemm_plans", "ocpg_bias_relu_dropout_bwd_slots", "ocpg_dropout_add_ln_bwd_slots", "ocpg_groupnorm_cl_work")
 
 
 def enable_kernel_timing(on=True):
@@ -150,6 +153,7 @@ def lib():
         L.ocpg_gemm_plans.restype = ctypes.c_longlong
         L.ocpg_bias_relu_dropout_bwd_slots.restype = ctypes.c_longlong
         L.ocpg_dropout_add_ln_bwd_slots.restype = ctypes.c_longlong
+        L.ocpg_groupnorm_cl_work.restype = ctypes.c_longlong
         _lib = _Lib(L)
     return _lib
 

@@ -30,6 +30,7 @@ from .deformable_transformer import build_deforamble_transformer
 from .matcher import build_matcher
 from .modules import LFMResizeAdaptive
 from .ops.functions.dynmask_func import dynamic_mask
+from .ops.functions.groupnorm_func import GroupNorm
 from .position_encoding import PositionEmbeddingSine1D
 from .postprocessors import build_postprocessors
 from .resample import bicubic_resize, bilinear_resize, nearest_upsample
@@ -128,10 +129,10 @@ class OCPG(nn.Module):
         chans = backbone.num_channels[-3:]
         proj, fft, fft_post = [], [], []
         for cin in chans:
-            proj.append(nn.Sequential(amp_cache.Conv2d(cin, hidden_dim, kernel_size=1), nn.GroupNorm(32, hidden_dim)))
+            proj.append(nn.Sequential(amp_cache.Conv2d(cin, hidden_dim, kernel_size=1), GroupNorm(32, hidden_dim)))
         cin = chans[-1]
         for _ in range(num_feature_levels - len(chans)):
-            proj.append(nn.Sequential(amp_cache.Conv2d(cin, hidden_dim, kernel_size=3, stride=2, padding=1), nn.GroupNorm(32, hidden_dim)))
+            proj.append(nn.Sequential(amp_cache.Conv2d(cin, hidden_dim, kernel_size=3, stride=2, padding=1), GroupNorm(32, hidden_dim)))
             cin = hidden_dim
         for _ in range(len(proj)):
             fft.append(LFMResizeAdaptive(hidden_dim, 7))

@@ -1,0 +1,64 @@
+"""Autograd binding of csrc/groupnorm.hip: the GroupNorm behind the input projections (reference models/ocpg.py:108-119), reading the
+channels-last map the projection GEMM wrote and writing the fp32 planes the LFM's FFTs read -- one launch each way."""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from ...._lib import check, lib
+
+_CODE = {torch.float32: 1, torch.bfloat16: 0, torch.float16: 2}
+
+
+def _scratch(x, groups):
+    """Per-tile partials of the tiled kernels (large maps); None when the one-launch kernels are used."""
+    n, c, h, w = x.shape
+    words = lib().ocpg_groupnorm_cl_work(n, h * w, c, groups)
+    return torch.empty(words, dtype=torch.float32, device=x.device) if words > 0 else None
+
+
+class GroupNormCLFunction(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups, eps):
+        n, c, h, w = x.shape
+        y = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+        mean = torch.empty((n, groups), dtype=torch.float32, device=x.device)
+        rstd = torch.empty((n, groups), dtype=torch.float32, device=x.device)
+        work = _scratch(x, groups)
+        check(lib().ocpg_groupnorm_cl_fwd(x.data_ptr(), _CODE[x.dtype], weight.data_ptr(), bias.data_ptr(), n, h * w, c, groups, float(eps),
+                                          y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), 0 if work is None else work.data_ptr(),
+                                          torch.cuda.current_stream().cuda_stream), "ocpg_groupnorm_cl_fwd")
+        ctx.save_for_backward(x, weight, mean, rstd)
+        ctx.groups = groups
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, weight, mean, rstd = ctx.saved_tensors
+        n, c, h, w = x.shape
+        gy = gy.float().contiguous()
+        dx = torch.empty_like(x)                       # preserves the channels-last strides
+        part = torch.empty((n, 2, c), dtype=torch.float32, device=x.device)
+        work = _scratch(x, ctx.groups)
+        check(lib().ocpg_groupnorm_cl_bwd(gy.data_ptr(), x.data_ptr(), _CODE[x.dtype], weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), n,
+                                          h * w, c, ctx.groups, dx.data_ptr(), part.data_ptr(), 0 if work is None else work.data_ptr(),
+                                          torch.cuda.current_stream().cuda_stream), "ocpg_groupnorm_cl_bwd")
+        dgb = part.sum(0)                              # one reduction for dgamma and dbeta
+        return dx, dgb[0], dgb[1], None, None
+
+
+def eligible(x, module):
+    return (x.is_cuda and x.dim() == 4 and x.dtype in _CODE and module.affine and module.num_channels == 8 * module.num_groups
+            and module.weight.dtype == torch.float32 and x.shape[0] > 0 and x.shape[2] * x.shape[3] > 0
+            and x.is_contiguous(memory_format=torch.channels_last))
+
+
+class GroupNorm(torch.nn.GroupNorm):
+    """nn.GroupNorm (same parameters / state_dict).  For a channels-last GPU map with groups of 8 channels (the reference's
+    GroupNorm(32, 256) on a projection output) the HIP pass; any other input takes ATen's group_norm.  The output is fp32
+    planes either way (autocast runs group_norm in fp32)."""
+
+    def forward(self, x):
+        if eligible(x, self):
+            return GroupNormCLFunction.apply(x, self.weight, self.bias, self.num_groups, self.eps)
+        return super().forward(x)

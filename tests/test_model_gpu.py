@@ -291,6 +291,44 @@ def test_small_linear_kernel(dev, xdt, r, cin, cout, bias, relu):
         assert (a - b_).abs().max().item() <= tol, (name, (a - b_).abs().max().item(), b_.abs().max().item())
 
 
+@pytest.mark.parametrize("xdt", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("n,c,h,w", [(10, 256, 45, 80), (2, 256, 50, 33), (1, 256, 25, 61), (3, 256, 23, 40), (2, 256, 6, 10), (1, 64, 1, 3), (2, 512, 17, 15)])
+def test_groupnorm_channels_last_kernel(dev, xdt, n, c, h, w):
+    """csrc/groupnorm.hip (channels-last map in its own dtype -> fp32 planes, one launch each way) == F.group_norm in fp32 on the same
+    stored values (what autocast computes for the reference's GroupNorm(32, 256), models/ocpg.py:108-119) and its autograd backward:
+    y, dgamma, dbeta to fp32 rounding; dx to fp32 rounding for fp32 maps and to one ulp of the map's dtype otherwise.  Maps of >= 1 500
+    pixels take the pixel-tiled kernels (two launches each way, ragged last tile included), smaller ones the one-launch kernels."""
+    from ocpg_amd.models.ops.functions.groupnorm_func import GroupNorm, eligible
+    gen = torch.Generator(device=dev).manual_seed(n * 1000 + c + h)
+    gn = GroupNorm(c // 8, c).to(dev)
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(c, device=dev, generator=gen))
+        gn.bias.copy_(torch.randn(c, device=dev, generator=gen))
+    x = (torch.randn(n, c, h, w, device=dev, generator=gen) * 1.5 + 0.7).to(xdt).contiguous(memory_format=torch.channels_last)
+    go = torch.randn(n, c, h, w, device=dev, generator=gen)
+    res = []
+    for mine in (True, False):
+        xi = x.clone(memory_format=torch.preserve_format).requires_grad_(True)
+        gn.zero_grad()
+        if mine:
+            assert eligible(xi, gn)
+            y = gn(xi)
+            assert y.is_contiguous() and y.dtype == torch.float32
+        else:
+            y = torch.nn.functional.group_norm(xi.float(), gn.num_groups, gn.weight, gn.bias, gn.eps)
+        (y * go).sum().backward()
+        if mine:
+            assert xi.grad.dtype == xdt and xi.grad.is_contiguous(memory_format=torch.channels_last)
+        res.append([y.detach(), xi.grad.float(), gn.weight.grad.clone(), gn.bias.grad.clone()])
+    ulp = {torch.float32: 2e-5, torch.bfloat16: 2 ** -7, torch.float16: 2 ** -10}[xdt]
+    for name, a, b_, tol in zip(("y", "dx", "dgamma", "dbeta"), res[0], res[1], (2e-5, ulp, 1e-4, 1e-4)):
+        bound = tol * b_.abs().max().item() + 1e-6
+        assert (a - b_).abs().max().item() <= bound, (name, (a - b_).abs().max().item(), b_.abs().max().item())
+    # a map that is not channels-last, or whose groups are not 8 channels wide, takes ATen's path (same module, same parameters)
+    assert not eligible(x.contiguous(), gn)
+    assert not eligible(x, torch.nn.GroupNorm(c // 4, c).to(dev))
+
+
 @pytest.mark.parametrize("amp", [None, torch.bfloat16])
 def test_lfm_channels_last_gate(dev, amp):
     """LFM with the gate output / inverse-FFT input in channels-last memory (csrc/spectral.hip c2p / p2c, 1x1 convs as GEMMs)
