@@ -572,6 +572,11 @@ def main():
     if mode != "eager":
         line["hipgraph"] = {"memset_nodes_replaced_by_kernel_nodes": step.memset_nodes_replaced, "checked_against_eager": True}
     line["ranks"] = {"world_size": dist.get_world_size() if world > 1 else 1, "backend": dist.get_backend() if world > 1 else None}
+    import ctypes
+    changed = ctypes.c_longlong(0)
+    line["gemm_plans"] = {"cached": int(_lib.lib().ocpg_gemm_plans()), "timed_at_first_use": int(_lib.lib().ocpg_gemm_tuned(ctypes.addressof(changed))),
+                          "left_first_heuristic_choice": int(changed.value),
+                          "candidates_rejected_for_differing_result": int(_lib.lib().ocpg_gemm_tune_rejected())}
     if rank == 0:
         rows = kernel_table(kt, lib_kt, a.clips_per_gpu * T_FRAMES, kt_steps, lib_steps)
         dom = next((r for r in rows if r["kernel"] in ("msda_bwd_enc_value", "msda_bwd_enc") and "frac" in r), None)

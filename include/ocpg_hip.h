@@ -169,6 +169,14 @@ int ocpg_gemm(const void* A, const void* B, void* C, const void* bias, int dtype
               long long M, long long N, long long K, long long lda, long long ldb, long long ldc, long long batch,
               long long strideA, long long strideB, long long strideC, float alpha, float beta, void* stream);
 long long ocpg_gemm_plans(void);      /* number of cached plans (diagnostics) */
+/* Plan selection: the first call of a plan that can be repeated without changing its result (beta == 0; the BN form with skip != D)
+ * times hipBLASLt's ranked candidates on the caller's operands (eager calls only, never inside a stream capture) and keeps the
+ * fastest one whose result agrees with the heuristic's single choice (what at::mm runs) to the rounding of the output type (8e-3 /
+ * 1e-3 of max |C| for bf16 / fp16 outputs).  bf16 / fp16 plans only: fp32 plans always keep the heuristic's choice (its ranked fp32
+ * list holds kernels that are 2e-3 off).  OCPG_GEMM_TUNE=0 keeps the heuristic's choice everywhere.  ocpg_gemm_tuned returns the number of plans timed on the current device and, in *changed (may be NULL),
+ * how many of them left the first choice; ocpg_gemm_tune_rejected the number of candidates dropped for a differing result. */
+long long ocpg_gemm_tuned(long long* changed);
+long long ocpg_gemm_tune_rejected(void);
 /* D[M,N] = act(scale[n] * (A W^T)[m,n] + shift[n] (+ skip[m,n])): the 1x1 conv + FrozenBatchNorm2d affine (+ identity) (+ ReLU) of a
  * Bottleneck (models/backbone.py:46-56 + torchvision's block) inside the GEMM epilogue (per-channel alpha vector, fp32 bias, ReLU,
  * beta = 1 on the skip operand).  A [M,K], W [N,K], skip / D [M,N] dense row-major, dtype 0/1/2; scale, shift fp32 [N].

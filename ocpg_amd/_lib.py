@@ -33,6 +33,8 @@ SIGNATURES = {
     "ocpg_conv3x3_mfma_dgrad": [_vp, _vp] + [_int] * 6 + [_vp, _vp],
     "ocpg_gemm": [_vp, _vp, _vp, _vp] + [_int] * 4 + [ctypes.c_longlong] * 10 + [ctypes.c_float, ctypes.c_float, _vp],
     "ocpg_gemm_plans": [],
+    "ocpg_gemm_tuned": [_vp],
+    "ocpg_gemm_tune_rejected": [],
     "ocpg_window_means3x3_fwd": [_vp, ctypes.c_longlong, _int, _int, _int, _vp, _vp],
     "ocpg_window_means3x3_bwd": [_vp, ctypes.c_longlong, _int, _int, _vp, _vp],
     "ocpg_small_linear_fwd": [_vp, _int, _vp, _vp, _int, _int, _int, _int, _vp, _vp],
@@ -85,7 +87,7 @@ SIGNATURES = {
 
 # ---- optional live kernel timing (bench.py): HIP events on the launch stream around every library call ----------
 _TIMING = {"on": False, "events": []}
-_UNTIMED = ("ocpg_gemm_plans", "ocpg_bias_relu_dropout_bwd_slots", "ocpg_dropout_add_ln_bwd_slots", "ocpg_groupnorm_cl_work")
+_UNTIMED = ("ocpg_gemm_plans", "ocpg_gemm_tuned", "ocpg_gemm_tune_rejected", "ocpg_bias_relu_dropout_bwd_slots", "ocpg_dropout_add_ln_bwd_slots", "ocpg_groupnorm_cl_work")
 
 
 def enable_kernel_timing(on=True):
@@ -151,6 +153,8 @@ def lib():
             fn.restype = ctypes.c_int
         L.ocpg_hip_version.restype = ctypes.c_char_p
         L.ocpg_gemm_plans.restype = ctypes.c_longlong
+        L.ocpg_gemm_tuned.restype = ctypes.c_longlong
+        L.ocpg_gemm_tune_rejected.restype = ctypes.c_longlong
         L.ocpg_bias_relu_dropout_bwd_slots.restype = ctypes.c_longlong
         L.ocpg_dropout_add_ln_bwd_slots.restype = ctypes.c_longlong
         L.ocpg_groupnorm_cl_work.restype = ctypes.c_longlong

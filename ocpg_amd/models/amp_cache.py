@@ -197,6 +197,11 @@ _SPLITS = {}
 _CHUNK_ROWS = float(os.environ.get("OCPG_SPLIT_ROWS", "1536"))      # rows per chunk the split aims for
 
 
+def _mm(a, b, trans_b=False, bias=None):
+    from .ops.functions.gemm_func import mm
+    return mm(a, b, trans_b, bias)
+
+
 def weight_grad(gy2, x2):
     """gy2 [M, Co], x2 [M, Ci] (row-major, M = pixels or tokens, large) -> gy2^T x2 [Co, Ci].
 
@@ -206,6 +211,9 @@ def weight_grad(gy2, x2):
     (tools/bench_conv1x1_bwd.py)."""
     m = gy2.shape[0]
     s = _split_rows(m) if SPLIT_K else 1
+    if gy2.is_cuda:
+        from .ops.functions.gemm_func import mm_tn
+        return mm_tn(gy2, x2, s)
     if s == 1:
         return torch.mm(gy2.t(), x2)
     return torch.bmm(gy2.view(s, m // s, -1).transpose(1, 2), x2.view(s, m // s, -1)).sum(0)
@@ -222,7 +230,7 @@ class Conv1x1AsGemm(torch.autograd.Function):
         n, c, h, wd = x.shape
         x2 = x.permute(0, 2, 3, 1).reshape(n * h * wd, c)
         w2 = w.reshape(w.shape[0], c)
-        y2 = torch.mm(x2, w2.t()) if bias is None else torch.addmm(bias, x2, w2.t())
+        y2 = _mm(x2, w2, True, bias)
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         return y2.view(n, h, wd, w.shape[0]).permute(0, 3, 1, 2)
@@ -235,7 +243,7 @@ class Conv1x1AsGemm(torch.autograd.Function):
         gy2 = gy.permute(0, 2, 3, 1).reshape(n * h * wd, co)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = torch.mm(gy2, w.reshape(co, c)).view(n, h, wd, c).permute(0, 3, 1, 2)
+            gx = _mm(gy2, w.reshape(co, c)).view(n, h, wd, c).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
             gw = weight_grad(gy2, x.permute(0, 2, 3, 1).reshape(n * h * wd, c)).view(w.shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -250,13 +258,13 @@ class TokenLinearFunction(torch.autograd.Function):
     def forward(ctx, x2, w, bias):
         ctx.save_for_backward(x2, w)
         ctx.has_bias = bias is not None
-        return torch.mm(x2, w.t()) if bias is None else torch.addmm(bias, x2, w.t())
+        return _mm(x2, w, True, bias)
 
     @staticmethod
     def backward(ctx, gy):
         x2, w = ctx.saved_tensors
         gy = gy.contiguous()
-        gx = torch.mm(gy, w) if ctx.needs_input_grad[0] else None
+        gx = _mm(gy, w) if ctx.needs_input_grad[0] else None
         gw = weight_grad(gy, x2) if ctx.needs_input_grad[1] else None
         gb = gy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return gx, gw, gb

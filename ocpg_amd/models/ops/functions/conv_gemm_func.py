@@ -10,6 +10,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from ...._lib import check, lib, stream_ptr
+from .gemm_func import mm
 
 _DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 ALWAYS = False      # tests: take the GEMM path for every eligible geometry, not only where it is faster
@@ -46,7 +47,7 @@ class Conv3x3AsGemm(Function):
             check(lib().ocpg_im2col3x3_nhwc(x.data_ptr(), n, h, wd, c, stride, dil, cols.data_ptr(), _DT[x.dtype], stream_ptr()),
                   "ocpg_im2col3x3_nhwc")
         w2 = w.permute(0, 2, 3, 1).reshape(co, 9 * c)             # a view when the weight is channels-last
-        y2 = torch.mm(cols, w2.t()) if bias is None else torch.addmm(bias, cols, w2.t())
+        y2 = mm(cols, w2, True, bias)
         ctx.save_for_backward(cols, w)
         ctx.geom = (n, c, h, wd, ho, wo, stride, dil, bias is not None)
         return y2.view(n, ho, wo, co).permute(0, 3, 1, 2)
@@ -61,7 +62,7 @@ class Conv3x3AsGemm(Function):
         gy2 = gy.permute(0, 2, 3, 1).reshape(n * ho * wo, co)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            dcols = torch.mm(gy2, w.permute(0, 2, 3, 1).reshape(co, 9 * c))
+            dcols = mm(gy2, w.permute(0, 2, 3, 1).reshape(co, 9 * c))
             gx_nhwc = torch.empty((n, h, wd, c), dtype=gy.dtype, device=gy.device)
             with torch.cuda.device(gy.device):
                 check(lib().ocpg_col2im3x3_nhwc(dcols.data_ptr(), n, h, wd, c, stride, dil, gx_nhwc.data_ptr(), _DT[gy.dtype],

@@ -10,6 +10,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from ...._lib import check, lib
+from .gemm_func import mm
 
 _DT = {torch.float32: 0, torch.bfloat16: 1}
 _calls = [0]
@@ -70,7 +71,7 @@ class LinearBiasReluDropout(Function):
     @staticmethod
     def forward(ctx, x2, w, b, p, rng, splits):
         seed, offset = rng if rng is not None else _rng()
-        h = torch.mm(x2, w.t())
+        h = mm(x2, w, True)
         r, c = h.shape
         check(lib().ocpg_bias_relu_dropout_fwd(h.data_ptr(), b.data_ptr(), r, c, float(p), seed, offset, _DT[h.dtype], h.data_ptr(), _st()),
               "ocpg_bias_relu_dropout_fwd")
@@ -92,7 +93,7 @@ class LinearBiasReluDropout(Function):
         check(lib().ocpg_bias_relu_dropout_bwd(gh.data_ptr(), h.data_ptr(), r, c, p, _DT[h.dtype], ga.data_ptr(), part.data_ptr(), _st()),
               "ocpg_bias_relu_dropout_bwd")
         dbias = part.sum(0)
-        gx = torch.mm(ga, w) if ctx.needs_input_grad[0] else None
+        gx = mm(ga, w) if ctx.needs_input_grad[0] else None
         gw = weight_grad(ga, x2) if ctx.needs_input_grad[1] else None
         return gx, gw, dbias.to(h.dtype) if ctx.needs_input_grad[2] else None, None, None, None
 

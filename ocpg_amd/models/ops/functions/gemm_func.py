@@ -5,7 +5,39 @@ import torch
 
 from ...._lib import check, lib
 
+import os
+
 _DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+# A/B switch: the path's large GEMMs (token Linears, 1x1 / im2col convolutions, their gradients) through the plan cache, whose plans
+# are timed at first use (csrc/gemm.hip: tune()); "0" = torch.mm / addmm / bmm (hipBLASLt's first heuristic choice)
+PLANNED = os.environ.get("OCPG_PLANNED_GEMM", "1") != "0"
+
+
+def _plain(t):
+    return t.dim() == 2 and t.is_cuda and t.dtype in _DT and t.shape[0] > 0 and t.shape[1] > 0 and (t.stride(1) == 1 or t.shape[1] == 1) \
+        and (t.shape[0] == 1 or t.stride(0) >= t.shape[1])
+
+
+def mm(a, b, trans_b=False, bias=None):
+    """a [M,K] @ (b [K,N] or, with trans_b, b [N,K]^T) (+ bias [N]): torch.mm / addmm semantics for 2-D GPU operands, through the
+    plan cache when the operands are plain row-major matrices of one dtype."""
+    if PLANNED and _plain(a) and _plain(b) and a.dtype == b.dtype and (bias is None or (bias.dtype == a.dtype and bias.is_contiguous())):
+        return gemm(a, b, False, trans_b, bias)
+    bb = b.t() if trans_b else b
+    return torch.mm(a, bb) if bias is None else torch.addmm(bias, a, bb)
+
+
+def mm_tn(a, b, splits=1):
+    """a [R,M]^T @ b [R,N] -> [M,N] (weight-gradient form), optionally reduced over `splits` row chunks (batched GEMM + sum)."""
+    if PLANNED and _plain(a) and _plain(b) and a.dtype == b.dtype:
+        if splits == 1:
+            return gemm(a, b, True, False)
+        if a.is_contiguous() and b.is_contiguous():
+            return gemm_tn_split(a, b, splits)
+    if splits == 1:
+        return torch.mm(a.t(), b)
+    r = a.shape[0]
+    return torch.bmm(a.view(splits, r // splits, -1).transpose(1, 2), b.view(splits, r // splits, -1)).sum(0)
 
 
 def _ld(t):
