@@ -23,6 +23,7 @@ rm -rf /tmp/prof_swint
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_swint -- python bench.py --backbone video_swin_t_p4w7 --steps 5 --warmup 3 --no-cpu-baseline --no-kernel-timing > $O/swint_under_rocprof.log 2>&1 || exit 1
 cp $(find /tmp/prof_swint -name "*kernel_stats.csv" | head -1) $O/swint_rocprofv3_kernel_stats.csv
 echo "[5] Swin-T done"
+[ -n "$SKIP_SWINB" ] && exit 0
 timeout -k 10 500 python bench.py --backbone video_swin_b_p4w7 --dtype fp16 --text roberta --frames 8 --height 480 --width 854 --clips-per-gpu 1 --steps 6 --warmup 3 --no-cpu-baseline > $O/bench_line_swinb_roberta_fp16.json 2> $O/bench_swinb.err || { tail -5 $O/bench_swinb.err; exit 1; }
 rm -rf /tmp/prof_swinb
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_swinb -- python bench.py --backbone video_swin_b_p4w7 --dtype fp16 --text roberta --frames 8 --height 480 --width 854 --clips-per-gpu 1 --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing > $O/swinb_under_rocprof.log 2>&1 || exit 1
