@@ -141,3 +141,24 @@ def test_level_embedding_function_matches_broadcast_adds():
     g1, = torch.autograd.grad((out * go).sum(), le)
     g2, = torch.autograd.grad((ref * go).sum(), le2)
     assert torch.allclose(g1, g2, atol=1e-5)
+
+
+def test_gemm_helpers_and_groupnorm_take_the_tensor_path_off_gpu():
+    """gemm_func.mm / mm_tn (plan-cache GEMMs on the GPU) and the input-projection GroupNorm module (HIP on channels-last GPU maps):
+    operands that are not eligible -- here: CPU tensors -- take torch's own ops with identical semantics; the module keeps
+    nn.GroupNorm's parameters / state_dict keys (checkpoints of the reference load unchanged)."""
+    from ocpg_amd.models.ops.functions import gemm_func
+    from ocpg_amd.models.ops.functions.groupnorm_func import GroupNorm, eligible
+    torch.manual_seed(0)
+    a, b, bias = torch.randn(24, 7), torch.randn(7, 5), torch.randn(5)
+    assert torch.allclose(gemm_func.mm(a, b), a @ b)
+    assert torch.allclose(gemm_func.mm(a, b.t().contiguous(), True, bias), a @ b + bias, atol=1e-6)
+    g, x = torch.randn(24, 6), torch.randn(24, 7)
+    assert torch.allclose(gemm_func.mm_tn(g, x), g.t() @ x, atol=1e-5)
+    assert torch.allclose(gemm_func.mm_tn(g, x, 4), g.t() @ x, atol=1e-5)
+    gn, ref = GroupNorm(4, 32), torch.nn.GroupNorm(4, 32)
+    assert list(gn.state_dict().keys()) == list(ref.state_dict().keys())
+    ref.load_state_dict(gn.state_dict())
+    m = torch.randn(2, 32, 5, 6).contiguous(memory_format=torch.channels_last)
+    assert not eligible(m, gn)
+    assert torch.equal(gn(m), ref(m))
