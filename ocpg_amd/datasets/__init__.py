@@ -1,0 +1,18 @@
+"""Input side of the path: what turns an annotated video into the `(samples, captions, targets)` the model
+and the criterion consume.
+
+  clip_sampling.py    which frames of a video make one training clip (reference datasets/ytvos.py:131-160)
+  targets.py          the per-clip `targets` dict and its invariants (datasets/ytvos.py:162-241, datasets/transforms_video.py:19-55)
+  clip_transforms.py  resize / crop / flip / normalise of a clip together with its targets (datasets/transforms_video.py)
+
+Everything works on tensors ([T, 3, H, W] clips, [T, H, W] masks) on whatever device they live on -- a clip can be decoded once, moved
+to the GPU and augmented there -- and takes an explicit `random.Random` so that a worker's stream of augmentations is reproducible.
+Dataset file formats (JPEG / PNG folders, meta_expressions.json, the weak-annotation h5 files) are out of scope: a dataset class hands
+`build_target` the arrays it read.
+"""
+from .clip_sampling import clips_of_video, sample_clip_indices
+from .clip_transforms import ClipPipeline, eval_pipeline, train_pipeline
+from .targets import build_target, check_target, mask_bounding_box
+
+__all__ = ["clips_of_video", "sample_clip_indices", "ClipPipeline", "eval_pipeline", "train_pipeline", "build_target", "check_target",
+           "mask_bounding_box"]

@@ -1,0 +1,168 @@
+"""Input side: clip sampling, the targets schema and the clip augmentations against the reference's rules
+(datasets/ytvos.py:99-283, datasets/transforms_video.py), stated as hand-derived cases -- the reference's transform module imports
+torchvision, which this image does not have, so no fixture could be generated from it."""
+import random
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from ocpg_amd.datasets import build_target, check_target, clips_of_video, eval_pipeline, mask_bounding_box, sample_clip_indices, train_pipeline
+from ocpg_amd.datasets import clip_transforms as ct
+from ocpg_amd.datasets.targets import has_instance
+from ocpg_amd.util.misc import collate_fn
+
+
+def _clip_and_target(t=5, h=360, w=640, empty_last=True):
+    g = torch.Generator().manual_seed(3)
+    clip = torch.randint(0, 256, (t, 3, h, w), dtype=torch.uint8, generator=g)
+    masks = torch.zeros(t, h, w)
+    masks[: t - 1 if empty_last else t, 100:200, 300:420] = 1
+    return clip, build_target(range(t), 7, masks, "The  Cat on the LEFT,  upright", weights=torch.rand(t, 45, 80, generator=g),
+                              weak_masks=torch.rand(t, 45, 80, generator=g))
+
+
+def test_anchor_frames_and_clip_sampling_rules():
+    assert clips_of_video(11, 5) == [0, 5, 10]                                   # ytvos.py:101
+    assert sample_clip_indices(30, 12, 1, random.Random(0)) == [12]
+    for seed in range(50):
+        rng = random.Random(seed)
+        vid_len, fid, n = rng.randint(1, 40), 0, rng.choice([2, 3, 5, 8])
+        fid = rng.randrange(vid_len)
+        idx = sample_clip_indices(vid_len, fid, n, random.Random(seed), train=True)
+        assert len(idx) == max(n, 3) if n != 1 else 1                            # num_frames 2 still yields the 3 local frames (:136-140)
+        assert fid in idx and all(0 <= i < vid_len for i in idx)
+        assert idx == sorted(idx) or idx == sorted(idx, reverse=True)            # random reverse (:160-162)
+        near = [i for i in idx if i != fid and abs(i - fid) <= 3]
+        assert len(near) >= min(2, vid_len - 1) or vid_len <= 2 or fid in (0, vid_len - 1)
+        assert idx == sample_clip_indices(vid_len, fid, n, random.Random(seed), train=True)      # reproducible
+    # enough frames outside the local window: the extra frames all come from outside [min, max] of the three local ones (:144-149)
+    idx = sample_clip_indices(100, 50, 8, random.Random(1), train=False)
+    local = [i for i in idx if 47 <= i <= 53]
+    assert len(local) >= 3 and all(i <= min(local) or i >= max(local) for i in idx if i not in local)
+    # a video shorter than what is missing: every frame at least once (:154-157)
+    idx = sample_clip_indices(3, 1, 8, random.Random(2), train=False)
+    assert len(idx) == 8 and set(idx) == {0, 1, 2} and idx == sorted(idx)
+    # evaluation never reverses
+    assert all(sample_clip_indices(20, 5, 5, random.Random(s), train=False) == sorted(sample_clip_indices(20, 5, 5, random.Random(s), train=False))
+               for s in range(20))
+
+
+def test_target_schema_of_a_clip():
+    clip, tg = _clip_and_target()
+    assert set(tg) == {"frames_idx", "labels", "boxes", "masks", "valid", "caption", "orig_size", "size", "weights", "weak_masks"}
+    assert tg["caption"] == "the cat on the left, upright"                        # lower-cased, single spaces (:126)
+    assert tg["boxes"][0].tolist() == [300.0, 100.0, 419.0, 199.0]                 # inclusive last row / column (:113-119,191-193)
+    assert tg["boxes"][4].tolist() == [0.0, 0.0, 0.0, 0.0] and tg["valid"].tolist() == [1, 1, 1, 1, 0]
+    assert tg["labels"].tolist() == [7] * 5 and tg["orig_size"].tolist() == [360, 640] == tg["size"].tolist()
+    assert tg["weights"].shape == (5, 360, 640)
+    assert has_instance(tg)
+    m = torch.zeros(6, 9)
+    m[2, 3] = 1
+    assert mask_bounding_box(m).tolist() == [3.0, 2.0, 3.0, 2.0] and mask_bounding_box(torch.zeros(4, 4)).tolist() == [0.0] * 4
+    # weak maps go to the frame size with align_corners=True: the corner values survive (:231-233)
+    w = torch.arange(12.0).view(1, 3, 4)
+    tg2 = build_target([0], 1, torch.ones(1, 9, 16), "x", weights=w)
+    assert tg2["weights"][0, 0, 0] == 0 and tg2["weights"][0, -1, -1] == 11 and tg2["weights"][0, 0, -1] == 3
+    # point supervision: the weak box replaces the mask box on visible frames only (:194-198)
+    wb = torch.tensor([[1.0, 2.0, 3.0, 4.0]] * 5)
+    tg3 = build_target(range(5), 7, tg["masks"], "x", weak_boxes=wb)
+    assert tg3["boxes"][0].tolist() == [1.0, 2.0, 3.0, 4.0] and tg3["boxes"][4].tolist() == [0.0] * 4
+
+
+def test_resize_rule_and_resized_targets():
+    # shorter side -> size, unless the longer side would pass max_size (transforms_video.py:214-240); truncation of the long side
+    assert ct.resize_size(480, 854, 360, 640) == (360, 640)
+    assert ct.resize_size(360, 640, 360, 640) == (360, 640)
+    assert ct.resize_size(720, 1280, 512, 640) == (360, 640)                      # 512 * 1280 / 720 > 640 -> size = round(640 * 720 / 1280)
+    assert ct.resize_size(500, 300, 400, None) == (666, 400)                      # int(400 * 500 / 300)
+    assert ct.resize_size(300, 500, 400, None) == (400, 666)
+    assert ct.resize_size(100, 200, (50, 30), None) == (30, 50)                   # an explicit (w, h) pair
+    clip, tg = _clip_and_target()
+    out, t2 = ct.resize_clip(clip, tg, 288, 640)
+    assert out.shape == (5, 3, 288, 512) and out.dtype == torch.float32 and t2["size"].tolist() == [288, 512]
+    assert torch.allclose(t2["boxes"][0], tg["boxes"][0] * 0.8)
+    assert t2["masks"].dtype == torch.bool and torch.equal(t2["masks"], F.interpolate(tg["masks"][:, None], (288, 512), mode="nearest")[:, 0] > 0.5)
+    assert t2["weights"].shape == (5, 288, 512) and tg["size"].tolist() == [360, 640]          # the input dict is not modified
+    # the image filter: identity at the same size, constant images stay constant, a 2x shrink of a checkerboard averages it
+    same, _ = ct.resize_clip(clip, None, 360, 640)
+    assert same is clip
+    board = (torch.arange(8)[:, None] + torch.arange(8)[None]) % 2 * 255.0
+    small, _ = ct.resize_clip(board.expand(1, 3, 8, 8).to(torch.uint8), None, (4, 4))
+    assert torch.allclose(small[..., 1:3, 1:3], torch.full((1, 3, 2, 2), 0.5), atol=1e-6) and (small - 0.5).abs().max() < 0.02
+    # against PIL's bilinear resize (what torchvision's F.resize runs on the reference's PIL frames): equal to PIL's uint8 rounding
+    import numpy as np
+    from PIL import Image
+    g = torch.Generator().manual_seed(5)
+    for (h, w), (oh, ow) in (((97, 131), (60, 81)), ((64, 48), (100, 75)), ((360, 640), (288, 512))):
+        # smooth + noisy content
+        img = (torch.rand(3, h, w, generator=g) * 60 + torch.linspace(0, 190, w)[None, None, :]).to(torch.uint8)
+        ours, _ = ct.resize_clip(img[None], None, (ow, oh))
+        pil = np.asarray(Image.fromarray(img.permute(1, 2, 0).numpy()).resize((ow, oh), Image.BILINEAR)).astype(np.float32)
+        d = np.abs(ours[0].permute(1, 2, 0).numpy() * 255.0 - pil)
+        assert d.max() <= 1.01 and d.mean() <= 0.4, (d.max(), d.mean())      # PIL rounds to uint8 after each of its two passes
+
+
+def test_crop_flip_check_and_normalise():
+    clip, tg = _clip_and_target()
+    out, t2 = ct.crop_clip(clip, tg, (150, 350, 120, 200))                         # top, left, height, width
+    assert out.shape == (5, 3, 120, 200) and t2["size"].tolist() == [120, 200] and t2["masks"].shape == (5, 120, 200)
+    assert t2["boxes"][0].tolist() == [0.0, 0.0, 69.0, 49.0] and t2["area"][0].item() == 69.0 * 49.0      # shifted and clipped (:135-141)
+    assert torch.equal(t2["masks"], tg["masks"][:, 150:270, 350:550])
+    # a window that misses the object: zero-area boxes -> invalid frames, boxes zeroed (:38-53)
+    _, t3 = ct.crop_clip(clip, tg, (0, 0, 90, 200))
+    t3 = check_target(t3)
+    assert t3["valid"].tolist() == [0] * 5 and float(t3["boxes"].abs().sum()) == 0 and not has_instance(t3)
+    assert check_target(dict(t2))["valid"].tolist() == [1, 1, 1, 1, 0]
+    # horizontal flip: x' = w - x with the corners swapped (:168-174); an involution on everything
+    f1, tf = ct.hflip_clip(clip, tg)
+    assert tf["boxes"][0].tolist() == [640 - 419.0, 100.0, 640 - 300.0, 199.0]
+    f2, tb = ct.hflip_clip(f1, tf)
+    assert torch.equal(f2, clip) and torch.equal(tb["boxes"], tg["boxes"]) and torch.equal(tb["masks"], tg["masks"])
+    assert torch.equal(tf["weights"], tg["weights"].flip(-1))
+    assert ct.swap_left_right("the left cat, right of the upright lefty") == "the right cat, left of the upleft righty"      # :582-583
+    # normalisation: (x / 255 - mean) / std; boxes -> cxcywh / (w, h, w, h) (:653-675)
+    x, tn = ct.normalize_clip(clip, tg)
+    px = clip[2, 1, 17, 33].item()
+    assert abs(x[2, 1, 17, 33].item() - (px / 255.0 - 0.456) / 0.224) < 1e-6
+    assert torch.allclose(tn["boxes"][0], torch.tensor([359.5 / 640, 149.5 / 360, 119.0 / 640, 99.0 / 360]))
+    assert torch.equal(tn["masks"], tg["masks"])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_training_pipeline_end_to_end(seed):
+    """ytvos.py:256-275 on a clip: consistent targets whatever branch the seed takes; same seed -> same sample; collate pads to /32."""
+    clip, tg = _clip_and_target()
+    pipe = train_pipeline(max_size=640)
+    x, t = pipe(clip, tg, random.Random(seed))
+    x2, t2 = pipe(clip, tg, random.Random(seed))
+    assert torch.equal(x, x2) and torch.equal(t["boxes"], t2["boxes"]) and t["caption"] == t2["caption"]
+    h, w = x.shape[-2:]
+    assert x.dtype == torch.float32 and x.shape[:2] == (5, 3) and t["size"].tolist() == [h, w] and t["masks"].shape == (5, h, w)
+    assert min(h, w) in ct.TRAIN_SCALES or max(h, w) <= 640
+    assert t["valid"].tolist()[4] == 0 and t["boxes"].min() >= 0 and t["boxes"].max() <= 1
+    assert t["caption"] in ("the cat on the left, upright", "the cat on the right, upleft")
+    flipped = t["caption"] != tg["caption"]
+    # the normalised box of a visible frame still frames that frame's mask (to the half-pixel the inclusive corners cost)
+    for k in range(4):
+        if t["valid"][k]:
+            ys, xs = torch.where(t["masks"][k])
+            cx, cy, bw, bh = (t["boxes"][k] * torch.tensor([w, h, w, h])).tolist()
+            assert abs((xs.min().item() + xs.max().item() + 1) / 2 - (cx + (0.5 if not flipped else 0.5))) <= 2.5
+            assert abs((ys.min().item() + ys.max().item() + 1) / 2 - (cy + 0.5)) <= 2.5
+            assert abs((xs.max() - xs.min()).item() - bw) <= 3 and abs((ys.max() - ys.min()).item() - bh) <= 3
+    # two differently augmented clips -> one padded batch (util/misc.py:299-379)
+    xb, tb = pipe(clip, tg, random.Random(seed + 100))
+    samples, targets = collate_fn([(x, t), (xb, tb)])
+    H, W = samples.tensors.shape[-2:]
+    assert H % 32 == 0 and W % 32 == 0 and samples.tensors.shape[:3] == (2, 5, 3) and len(targets) == 2
+    assert not samples.mask[0, :, :h, :w].any() and samples.mask[0, :, h:, :].all() and samples.mask[0, :, :, w:].all()
+    assert torch.equal(samples.tensors[0, :, :, :h, :w], x)
+
+
+def test_evaluation_pipeline():
+    clip = torch.randint(0, 256, (3, 3, 480, 854), dtype=torch.uint8)
+    x, t = eval_pipeline()(clip, None)
+    assert x.shape == (3, 3, 360, 640) and t is None                              # ytvos.py:278-282
+    x, _ = eval_pipeline()(torch.rand(2, 3, 360, 640), None)
+    assert x.shape == (2, 3, 360, 640)
