@@ -2,7 +2,8 @@
 and the criterion consume.
 
   clip_sampling.py    which frames of a video make one training clip (reference datasets/ytvos.py:131-160)
-  targets.py          the per-clip `targets` dict and its invariants (datasets/ytvos.py:162-241, datasets/transforms_video.py:19-55)
+  targets.py          the per-clip `targets` dict, its invariants and the weak-supervision masks / boxes from heat maps
+                      (datasets/ytvos.py:22-38,162-241, datasets/transforms_video.py:19-55)
   clip_transforms.py  resize / crop / flip / normalise of a clip together with its targets (datasets/transforms_video.py)
 
 Everything works on tensors ([T, 3, H, W] clips, [T, H, W] masks) on whatever device they live on -- a clip can be decoded once, moved
@@ -12,7 +13,7 @@ Dataset file formats (JPEG / PNG folders, meta_expressions.json, the weak-annota
 """
 from .clip_sampling import clips_of_video, sample_clip_indices
 from .clip_transforms import ClipPipeline, eval_pipeline, train_pipeline
-from .targets import build_target, check_target, mask_bounding_box
+from .targets import build_target, check_target, mask_bounding_box, weak_targets_from_heatmaps
 
 __all__ = ["clips_of_video", "sample_clip_indices", "ClipPipeline", "eval_pipeline", "train_pipeline", "build_target", "check_target",
-           "mask_bounding_box"]
+           "mask_bounding_box", "weak_targets_from_heatmaps"]

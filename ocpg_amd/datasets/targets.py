@@ -29,6 +29,23 @@ def mask_bounding_box(mask: Tensor) -> Tensor:
     return torch.stack([xs[0], ys[0], xs[-1], ys[-1]]).to(torch.float32)
 
 
+def weak_targets_from_heatmaps(heatmaps: Tensor, instance_index: int, thres: float = 0.5):
+    """Weak supervision of one frame (reference datasets/ytvos.py:22-38): heatmaps [n, h, w], one per annotated object -> the mask of
+    the pixels where object `instance_index` beats every other object AND the constant background plane `thres` (arg-max over n + 1
+    planes, first maximum wins), and the xyxy box around it built from its projections: extent = number of occupied columns / rows,
+    centre = their centre of mass (so a mask with gaps gets a box tighter than its hull).  An empty mask gives the zero box."""
+    n, h, w = heatmaps.shape
+    planes = torch.cat([heatmaps, torch.full((1, h, w), thres, dtype=heatmaps.dtype, device=heatmaps.device)], dim=0)
+    mask = (planes.argmax(dim=0) == instance_index).to(torch.float32)
+    cols, rows = mask.amax(0), mask.amax(1)                        # occupied columns [w] / rows [h]
+    bw, bh = cols.sum(), rows.sum()
+    xs = torch.arange(w, dtype=torch.float32, device=mask.device)
+    ys = torch.arange(h, dtype=torch.float32, device=mask.device)
+    cx = (cols * xs).sum() / bw.clamp(min=1e-6)
+    cy = (rows * ys).sum() / bh.clamp(min=1e-6)
+    return mask, torch.stack([cx - 0.5 * bw, cy - 0.5 * bh, cx + 0.5 * bw, cy + 0.5 * bh])
+
+
 def build_target(frames_idx, category_id: int, masks: Tensor, caption: str, weights: Optional[Tensor] = None,
                  weak_masks: Optional[Tensor] = None, weak_boxes: Optional[Tensor] = None) -> dict:
     """masks [T, H, W] (the referred object's binary masks on the raw frames) -> the targets dict of ytvos.py:215-229.

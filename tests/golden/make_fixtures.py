@@ -609,11 +609,111 @@ def gen_e2e_swin():
     save("e2e_swin", meta, **arrays)
 
 
+def gen_clip_transforms():
+    """Input side (row f4): the reference's OWN target arithmetic of datasets/transforms_video.py (resize incl. its size rule, crop,
+    Check, hflip + caption swap, Normalize) and datasets/ytvos.py:22-38 (weight2mask) on seeded synthetic clips.  Those modules
+    import torchvision / cv2 / h5py at module level; the name stubs below add the five torchvision.transforms.functional calls the
+    image side needs as their PIL one-liners (what torchvision itself does for PIL inputs) -- the image pixels in this fixture are
+    therefore PIL's, the target tensors are the reference's."""
+    import random as pyrandom
+
+    from PIL import Image
+    ref_import.install()
+    tv = sys.modules["torchvision"]
+
+    def to_tensor(im):
+        return torch.from_numpy(np.asarray(im).copy()).permute(2, 0, 1).float() / 255.0
+
+    def normalize(x, mean, std):
+        return (x - torch.tensor(mean).view(3, 1, 1)) / torch.tensor(std).view(3, 1, 1)
+
+    tvf = ref_import._mod("torchvision.transforms.functional",
+                          crop=lambda im, i, j, h, w: im.crop((j, i, j + w, i + h)),
+                          hflip=lambda im: im.transpose(Image.FLIP_LEFT_RIGHT),
+                          vflip=lambda im: im.transpose(Image.FLIP_TOP_BOTTOM),
+                          resize=lambda im, size: im.resize((size[1], size[0]), Image.BILINEAR),
+                          to_tensor=to_tensor, normalize=normalize, pad=None)
+    tv.transforms.functional = tvf
+    tv.transforms.RandomCrop = type("RandomCrop", (), {})
+    tv.transforms.RandomErasing = type("RandomErasing", (), {})
+    for name in ("cv2", "h5py"):
+        if name not in sys.modules:
+            ref_import._mod(name)
+    import importlib.machinery
+    import types
+    pkg = types.ModuleType("datasets")           # bypass datasets/__init__.py (it imports every dataset: torchvision.io, pycocotools, ...)
+    pkg.__path__ = [os.path.join(ref_import.REF, "datasets")]
+    pkg.__spec__ = importlib.machinery.ModuleSpec("datasets", None, is_package=True)
+    sys.modules["datasets"] = pkg
+    import datasets.transforms_video as RT
+    import datasets.ytvos as RY
+
+    g = torch.Generator().manual_seed(11)
+    T_, H, W = 3, 96, 160
+    frames = torch.randint(0, 256, (T_, H, W, 3), dtype=torch.uint8, generator=g)
+    frames = (frames.float() * 0.25 + torch.linspace(0, 190, W)[None, None, :, None]).to(torch.uint8)      # texture on a ramp
+    clip = [Image.fromarray(f.numpy()) for f in frames]
+    masks = torch.zeros(T_, H, W)
+    masks[0, 20:50, 30:90] = 1
+    masks[1, 40:70, 100:150] = 1                      # frame 2 has no object
+    boxes = torch.tensor([[30.0, 20, 89, 49], [100, 40, 149, 69], [0, 0, 0, 0]])
+    target = {"frames_idx": torch.arange(T_), "labels": torch.full((T_,), 4), "boxes": boxes, "masks": masks,
+              "valid": torch.tensor([1, 1, 0]), "caption": "the left zebra, right of the upright lefty", "orig_size": torch.as_tensor([H, W]),
+              "size": torch.as_tensor([H, W]), "weights": torch.rand(T_, H, W, generator=g), "weak_masks": torch.rand(T_, H, W, generator=g)}
+    arrays = {"frames": frames, "masks": masks, "boxes": boxes, "weights": target["weights"], "weak_masks": target["weak_masks"]}
+    meta = {"caption": target["caption"], "cases": {}}
+
+    def pack(tag, imgs, t):
+        if imgs is not None:       # PIL frames are uint8: stored as such (the normalised clip stays float)
+            arrays[tag + "_img"] = torch.stack([im if torch.is_tensor(im) else torch.from_numpy(np.asarray(im).copy()).permute(2, 0, 1) for im in imgs])
+        for k in ("boxes", "masks", "valid", "size", "weights", "weak_masks", "area"):
+            if k in t and (k not in ("weights", "weak_masks") or tag in ("rs72", "crop_in", "flip")):
+                arrays[f"{tag}_{k}"] = t[k].to(torch.uint8) if (t[k].dtype == torch.bool or k == "masks") else t[k]
+
+    resize_cases = {"rs72": (72, 100), "rs64": (64, None), "rs128": (128, 200), "rs_pair": ((50, 30), None), "rs_same": (96, None)}
+    for tag, (size, max_size) in resize_cases.items():
+        imgs, t = RT.resize(clip, dict(target), size, max_size)
+        pack(tag, imgs, t)
+        meta["cases"][tag] = {"size": size, "max_size": max_size, "out_hw": [imgs[0].size[1], imgs[0].size[0]]}
+    # the size rule alone on shapes of the real datasets (w, h order as PIL reports it)
+    rule = []
+    for (h, w, size, max_size) in [(480, 854, 360, 640), (360, 640, 360, 640), (720, 1280, 512, 640), (720, 1280, 288, 640), (500, 300, 400, None),
+                                   (300, 500, 600, None), (1080, 1920, 448, 640), (640, 480, 480, 640), (333, 777, 392, 640), (405, 720, 360, 640)]:
+        probe = [Image.new("RGB", (w, h))]
+        out, _ = RT.resize(probe, None, size, max_size)
+        rule.append([h, w, size, -1 if max_size is None else max_size, out[0].size[1], out[0].size[0]])
+    arrays["size_rule"] = torch.tensor(rule)
+    crop_cases = {"crop_in": (10, 20, 60, 90), "crop_miss": (60, 0, 30, 25), "crop_edge": (30, 60, 66, 100)}
+    for tag, region in crop_cases.items():
+        imgs, t = RT.crop(clip, dict(target), region)
+        imgs, t = RT.Check()(imgs, t)
+        pack(tag, imgs, t)
+        meta["cases"][tag] = {"region": list(region)}
+    imgs, t = RT.hflip(clip, dict(target))
+    pack("flip", imgs, t)
+    pyrandom.seed(0)
+    _, t = RT.RandomHorizontalFlip(p=1.0)(clip, dict(target))
+    meta["flipped_caption"] = t["caption"]
+    tens, _ = RT.ToTensor()(clip, dict(target))
+    imgs, t = RT.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])(tens, dict(target))
+    pack("norm", imgs, t)
+    # weak supervision: heat maps -> instance mask + box (ytvos.py:22-38)
+    heat = torch.rand(3, 40, 64, generator=g) * 0.45
+    heat[0, 5:20, 10:30] += 0.5
+    heat[1, 15:35, 25:60] += 0.5
+    heat[2, 0:4, 0:4] += 0.1                                   # never beats the 0.5 background plane
+    arrays["heat"] = heat
+    for k in range(3):
+        m, b = RY.weight2mask(heat, k)
+        arrays[f"w2m_mask{k}"], arrays[f"w2m_box{k}"] = m, b
+    save("clip_transforms", meta, **arrays)
+
+
 GENS = {"msda_testpy": gen_msda_testpy, "msda_cases": gen_msda_cases, "msda_module": gen_msda_module,
         "transformer": gen_transformer, "lfm": gen_lfm, "fusion": gen_fusion, "dynmask_mso": gen_dynmask_mso,
         "matcher_crit": gen_matcher_crit, "e2e_tiny": gen_e2e_tiny, "e2e_d32": gen_e2e_d32, "e2e_cfg1": gen_e2e_cfg1,
         "train_step": gen_train_step,
-        "swin3d": gen_swin3d, "swin_n392": gen_swin_n392, "e2e_swin": gen_e2e_swin}
+        "swin3d": gen_swin3d, "swin_n392": gen_swin_n392, "e2e_swin": gen_e2e_swin, "clip_transforms": gen_clip_transforms}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GENS)

@@ -1,6 +1,7 @@
-"""Input side: clip sampling, the targets schema and the clip augmentations against the reference's rules
-(datasets/ytvos.py:99-283, datasets/transforms_video.py), stated as hand-derived cases -- the reference's transform module imports
-torchvision, which this image does not have, so no fixture could be generated from it."""
+"""Input side: clip sampling, the targets schema and the clip augmentations against the reference
+(datasets/ytvos.py:22-283, datasets/transforms_video.py): the target arithmetic against tests/golden/clip_transforms.npz (the
+reference's own functions run on seeded clips), the randomised parts (sampling, pipeline composition) as hand-derived cases of its
+rules, the image filter against PIL."""
 import random
 
 import pytest
@@ -166,3 +167,58 @@ def test_evaluation_pipeline():
     assert x.shape == (3, 3, 360, 640) and t is None                              # ytvos.py:278-282
     x, _ = eval_pipeline()(torch.rand(2, 3, 360, 640), None)
     assert x.shape == (2, 3, 360, 640)
+
+
+def test_target_arithmetic_against_the_reference_fixture():
+    """tests/golden/clip_transforms.npz = the reference's own datasets/transforms_video.py (resize with its size rule, crop + Check,
+    hflip + caption swap, Normalize) and datasets/ytvos.py:22-38 (weight2mask) run on seeded clips (make_fixtures.py:
+    gen_clip_transforms): boxes / areas / sizes / validity / masks / weak maps equal; resized pixels equal PIL's to its uint8 rounding."""
+    from conftest import Golden
+    from ocpg_amd.datasets import weak_targets_from_heatmaps
+    gold = Golden("clip_transforms")
+    a, meta = gold, gold.meta
+    t = lambda k: gold[k]
+    clip = t("frames").permute(0, 3, 1, 2).contiguous()                            # [T, 3, H, W] uint8
+    base = {"boxes": t("boxes"), "masks": t("masks"), "valid": torch.tensor([1, 1, 0]), "caption": meta["caption"],
+            "size": torch.tensor(list(clip.shape[-2:])), "weights": t("weights"), "weak_masks": t("weak_masks")}
+
+    def same_targets(tag, got, maps=False):
+        assert torch.allclose(got["boxes"], t(tag + "_boxes"), atol=1e-5), tag
+        assert got["size"].tolist() == t(tag + "_size").tolist(), tag
+        assert torch.equal(got["masks"].to(torch.uint8), t(tag + "_masks")), tag
+        if tag + "_area" in a:
+            assert torch.allclose(got["area"], t(tag + "_area"), rtol=1e-6), tag
+        if tag + "_valid" in a:
+            assert got["valid"].tolist() == t(tag + "_valid").tolist(), tag
+        if maps:
+            for k in ("weights", "weak_masks"):
+                assert torch.allclose(got[k], t(f"{tag}_{k}"), atol=1e-6), (tag, k)
+
+    for h, w, size, max_size, oh, ow in t("size_rule").tolist():                    # transforms_video.py:214-240
+        assert ct.resize_size(h, w, size, None if max_size < 0 else max_size) == (oh, ow)
+    for tag, case in meta["cases"].items():
+        if tag.startswith("rs"):
+            size = tuple(case["size"]) if isinstance(case["size"], list) else case["size"]
+            out, got = ct.resize_clip(clip, dict(base), size, case["max_size"])
+            assert list(out.shape[-2:]) == case["out_hw"], tag
+            same_targets(tag, got, maps=tag == "rs72")
+            d = (ct.as_float_clip(out) * 255.0 - t(tag + "_img").float()).abs()
+            assert d.max() <= 1.01 and d.mean() <= 0.4, (tag, d.max(), d.mean())
+        else:
+            out, got = ct.crop_clip(clip, dict(base), tuple(case["region"]))
+            got = check_target(got)
+            same_targets(tag, got, maps=tag == "crop_in")
+            assert torch.equal(out, t(tag + "_img")), tag
+    out, got = ct.hflip_clip(clip, dict(base))
+    same_targets("flip", got, maps=True)
+    assert torch.equal(out, t("flip_img")) and ct.swap_left_right(meta["caption"]) == meta["flipped_caption"]
+    out, got = ct.normalize_clip(clip, dict(base))
+    same_targets("norm", got)
+    assert torch.allclose(out, t("norm_img"), atol=2e-6)
+    heat = t("heat")
+    for k in range(3):                                                               # ytvos.py:22-38
+        m, b = weak_targets_from_heatmaps(heat, k)
+        assert torch.equal(m, t(f"w2m_mask{k}")) and torch.allclose(b, t(f"w2m_box{k}"), atol=1e-5), k
+    # nothing beats the background plane -> empty mask, zero box
+    m, b = weak_targets_from_heatmaps(heat * 0.1, 0)
+    assert float(m.sum()) == 0 and b.tolist() == [0.0, 0.0, 0.0, 0.0]
