@@ -2,6 +2,7 @@
 (datasets/ytvos.py:22-283, datasets/transforms_video.py): the target arithmetic against tests/golden/clip_transforms.npz (the
 reference's own functions run on seeded clips), the randomised parts (sampling, pipeline composition) as hand-derived cases of its
 rules, the image filter against PIL."""
+import os
 import random
 
 import pytest
@@ -222,3 +223,118 @@ def test_target_arithmetic_against_the_reference_fixture():
     # nothing beats the background plane -> empty mask, zero box
     m, b = weak_targets_from_heatmaps(heat * 0.1, 0)
     assert float(m.sum()) == 0 and b.tolist() == [0.0, 0.0, 0.0, 0.0]
+
+
+def _write_tiny_dataset(root, videos=("vidA", "vidB"), n_frames=7, h=48, w=64):
+    """A Ref-YouTube-VOS style tree with two objects per video; object 2 of vidB never appears (exercises the re-draw)."""
+    import json
+    import os
+    import numpy as np
+    from PIL import Image
+    g = np.random.default_rng(0)
+    meta, exps = {"videos": {}}, {"videos": {}}
+    for v in videos:
+        names = ["%05d" % (5 * i) for i in range(n_frames)]
+        for sub in ("JPEGImages", "Annotations", "AnnotationsWeakly"):
+            os.makedirs(os.path.join(root, "train", sub, v), exist_ok=True)
+        for i, n in enumerate(names):
+            Image.fromarray(g.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(os.path.join(root, "train", "JPEGImages", v, n + ".jpg"))
+            lab = np.zeros((h, w), dtype=np.uint8)
+            lab[10:30, 5 + 2 * i:25 + 2 * i] = 1
+            if v == "vidA":
+                lab[35:45, 40:60] = 2
+            ann = Image.fromarray(lab)
+            ann.putpalette([0, 0, 0, 128, 0, 0, 0, 128, 0] + [0] * 759)
+            ann.save(os.path.join(root, "train", "Annotations", v, n + ".png"))
+            heat = np.zeros((2, h // 2, w // 2), dtype=np.float32)
+            heat[0, 5:15, 3 + i:13 + i] = 0.9
+            heat[1, 17:22, 20:30] = 0.8
+            np.savez(os.path.join(root, "train", "AnnotationsWeakly", v, n + ".npz"), heatPoint=heat, obj_ids=np.array([1, 2]))
+        meta["videos"][v] = {"objects": {"1": {"category": "zebra"}, "2": {"category": "ape"}}}
+        exps["videos"][v] = {"frames": names, "expressions": {"0": {"exp": "The Zebra  on the left", "obj_id": "1"},
+                                                              "1": {"exp": "an ape", "obj_id": "2"}}}
+    os.makedirs(os.path.join(root, "meta_expressions", "train"), exist_ok=True)
+    with open(os.path.join(root, "train", "meta.json"), "w") as f:
+        json.dump(meta, f)
+    with open(os.path.join(root, "meta_expressions", "train", "meta_expressions.json"), "w") as f:
+        json.dump(exps, f)
+    return names
+
+
+def test_folder_dataset_yields_model_ready_clips(tmp_path):
+    """datasets/ytvos.py:79-243 on a synthetic folder tree: index records, decoded clips, targets incl. the weak maps, the re-draw of
+    samples whose object never shows, reproducibility per (seed, index), and the padded batch."""
+    from ocpg_amd.datasets import ClipPipeline
+    from ocpg_amd.datasets.video_folders import RefVideoClips, RefVideoIndex, read_frames, read_object_masks
+    root = str(tmp_path)
+    names = _write_tiny_dataset(root)
+    index = RefVideoIndex(root, "train", num_frames=3)
+    assert len(index) == 2 * 2 * 3 and index.category_ids == {"ape": 0, "zebra": 1}          # 2 videos x 2 expressions x anchors 0, 3, 6
+    assert [m["frame_id"] for m in index.metas[:3]] == [0, 3, 6] and index.metas[0]["obj_id"] == 1
+    clip = read_frames(os.path.join(root, "train", "JPEGImages", "vidA"), names[:2])
+    assert clip.shape == (2, 3, 48, 64) and clip.dtype == torch.uint8
+    m = read_object_masks(os.path.join(root, "train", "Annotations", "vidA"), names[:2], 2)
+    assert m.shape == (2, 48, 64) and float(m[0, 35:45, 40:60].min()) == 1 and float(m.sum()) == 2 * 200
+    small = ClipPipeline([lambda c, t, r: ct.resize_clip(c, t, 32, 64), lambda c, t, r: (c, check_target(t)), lambda c, t, r: ct.normalize_clip(c, t)])
+    for supervision in ("box", "point"):
+        ds = RefVideoClips(root, "train", 3, small, supervision=supervision, seed=7)
+        x, t = ds[0]
+        assert x.shape == (3, 3, 32, 42) and x.dtype == torch.float32 and t["caption"] == "the zebra on the left"
+        assert t["masks"].shape == (3, 32, 42) and t["weights"].shape == (3, 32, 42) and t["weak_masks"].shape == (3, 32, 42)
+        assert t["valid"].tolist() == [1, 1, 1] and t["labels"].tolist() == [1, 1, 1] and 0 in t["frames_idx"].tolist()
+        assert float(t["boxes"].min()) >= 0 and float(t["boxes"].max()) <= 1
+        x2, t2 = ds[0]
+        assert torch.equal(x, x2) and torch.equal(t["boxes"], t2["boxes"])                 # same (seed, index) -> same sample
+    # the ape is absent from vidB: those records re-draw until a clip shows its object (ytvos.py:240-243)
+    ape_b = [i for i, m in enumerate(ds.index.metas) if m["video"] == "vidB" and m["obj_id"] == 2]
+    x, t = ds[ape_b[0]]
+    assert bool((t["valid"] == 1).any())
+    samples, targets = collate_fn([ds[0], ds[4]])
+    assert samples.tensors.shape == (2, 3, 3, 32, 64) and samples.mask.shape == (2, 3, 32, 64) and len(targets) == 2
+
+
+def test_inference_writes_the_competition_png_layout(tmp_path):
+    """inference_ytvos.py:168-245 / inference_davis.py:253-268 with a stand-in model: per expression one 0/255 PNG per frame at the
+    ORIGINAL resolution, the 'validation minus test' video filter, and palette label maps of merged objects."""
+    import json
+    import numpy as np
+    from PIL import Image
+    from ocpg_amd import inference
+    from ocpg_amd.datasets.video_folders import expressions_of_split
+    root = str(tmp_path)
+    names = _write_tiny_dataset(root)
+    os.makedirs(os.path.join(root, "meta_expressions", "test"), exist_ok=True)
+    with open(os.path.join(root, "meta_expressions", "test", "meta_expressions.json"), "w") as f:
+        json.dump({"videos": {"vidB": {}}}, f)
+    assert list(expressions_of_split(root, "train", exclude_split="test")) == ["vidA"]
+
+    class Stub(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+
+        def forward(self, clips, captions, targets):
+            t, _, h, w = clips[0].shape
+            assert (h, w) == (360, 480) and targets[0]["size"].tolist() == [360, 480]      # 48 x 64 frames: shorter side -> 360
+            masks = torch.full((1, t, 2, h, w), -10.0)
+            if "zebra" in captions[0].lower():
+                masks[:, :, 1, : h // 2] = 10.0                                            # query 1: top half
+            else:
+                masks[:, :, 0, :, : w // 4] = 10.0                                         # query 0: left quarter
+            logits = torch.tensor([[-3.0], [3.0]] if "zebra" in captions[0].lower() else [[3.0], [-3.0]]).expand(1, t, 2, 1)
+            return {"pred_logits": logits, "pred_masks": masks}
+
+    out = str(tmp_path / "out")
+    n = inference.write_expression_masks(Stub(), root, "train", out, exclude_split="test")
+    assert n == 2 * len(names)
+    top = np.asarray(Image.open(os.path.join(out, "Annotations", "vidA", "0", names[3] + ".png")))
+    left = np.asarray(Image.open(os.path.join(out, "Annotations", "vidA", "1", names[0] + ".png")))
+    assert top.shape == (48, 64) and top.dtype == np.uint8 and set(np.unique(top)) == {0, 255}
+    assert top[:23].min() == 255 and top[25:].max() == 0 and left[:, :15].min() == 255 and left[:, 17:].max() == 0
+    assert not os.path.exists(os.path.join(out, "Annotations", "vidB"))
+    labels = inference.merge_objects(torch.stack([torch.from_numpy(top / 255.0).float()[None], torch.from_numpy(left / 255.0).float()[None]]))
+    inference.write_label_maps(labels, str(tmp_path / "davis" / "anno_0" / "vidA"))
+    img = Image.open(str(tmp_path / "davis" / "anno_0" / "vidA" / "00000.png"))
+    assert img.mode == "P" and set(np.unique(np.asarray(img))) == {0, 1, 2} and np.asarray(img)[40, 40] == 0
+    assert torch.equal(torch.from_numpy(np.asarray(img).copy()), labels[0])
+    assert inference.label_palette()[:12] == [0, 0, 0, 128, 0, 0, 0, 128, 0, 128, 128, 0]              # the VOC / DAVIS colours
