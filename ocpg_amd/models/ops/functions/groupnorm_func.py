@@ -50,7 +50,7 @@ class GroupNormCLFunction(Function):
 def eligible(x, module):
     return (x.is_cuda and x.dim() == 4 and x.dtype in _CODE and module.affine and module.num_channels == 8 * module.num_groups
             and module.weight.dtype == torch.float32 and x.shape[0] > 0 and x.shape[2] * x.shape[3] > 0
-            and x.is_contiguous(memory_format=torch.channels_last))
+            and x.is_contiguous(memory_format=torch.channels_last) and x.data_ptr() % 16 == 0)      # 16-byte pixel-octet loads
 
 
 class GroupNorm(torch.nn.GroupNorm):
