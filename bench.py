@@ -414,7 +414,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--eager", action="store_true",
                     help="launch every kernel eagerly (DistributedDataParallel for N > 1).  Default: forward + criterion + backward "
-                         "replayed as ONE HIP graph (the eager step is host-bound: ~2 600 launches, 51 ms vs 40 ms); the graph is "
+                         "replayed as ONE HIP graph (the eager step is host-bound: ~2 600 launches, 45 ms vs 40 ms); the graph is "
                          "checked against an eager step before the timed region and bench.py falls back to eager if that fails.")
     ap.add_argument("--graph", action="store_true", help="(default since round 2; kept for old command lines)")
     a = ap.parse_args()
