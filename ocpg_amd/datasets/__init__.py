@@ -6,6 +6,7 @@ and the criterion consume.
                       (datasets/ytvos.py:22-38,162-241, datasets/transforms_video.py:19-55)
   clip_transforms.py  resize / crop / flip / normalise of a clip together with its targets (datasets/transforms_video.py)
   video_folders.py    Ref-YouTube-VOS / Ref-DAVIS folder readers and the training-clip dataset (datasets/ytvos.py:41-243)
+  prefetch.py         host -> device staging of batches on a side stream (engine.py:41-44 does it on the compute stream)
 
 Everything works on tensors ([T, 3, H, W] clips, [T, H, W] masks) on whatever device they live on -- a clip can be decoded once, moved
 to the GPU and augmented there -- and takes an explicit `random.Random` so that a worker's stream of augmentations is reproducible.

@@ -338,3 +338,23 @@ def test_inference_writes_the_competition_png_layout(tmp_path):
     assert img.mode == "P" and set(np.unique(np.asarray(img))) == {0, 1, 2} and np.asarray(img)[40, 40] == 0
     assert torch.equal(torch.from_numpy(np.asarray(img).copy()), labels[0])
     assert inference.label_palette()[:12] == [0, 0, 0, 128, 0, 0, 0, 128, 0, 128, 128, 0]              # the VOC / DAVIS colours
+
+
+def test_device_prefetcher_passes_batches_through_in_order():
+    """datasets/prefetch.py off the GPU: every batch once, in order, captions split off before the targets lose their strings
+    (engine.py:41-44), the NestedTensor's mask tag kept, `on_device` applied."""
+    from ocpg_amd.datasets.prefetch import DevicePrefetcher
+    clip, tg = _clip_and_target(t=2, h=40, w=56, empty_last=False)
+    pipe = eval_pipeline(size=32, max_size=64)
+    batches = []
+    for k in range(3):
+        x, t = ct.normalize_clip(*ct.resize_clip(clip, dict(tg, caption="clip %d" % k), 32 + 8 * k, 96))
+        batches.append(collate_fn([(x, t), (x.flip(-1), dict(t))]))
+    seen = []
+    pf = DevicePrefetcher(batches, "cpu", on_device=lambda c, t: (c, [dict(d, seen=torch.tensor(1)) for d in t]))
+    assert len(pf) == 3
+    for k, (samples, captions, targets) in enumerate(pf):
+        assert captions == ["clip %d" % k] * 2 and all("caption" not in t and int(t["seen"]) == 1 for t in targets)
+        assert torch.equal(samples.tensors, batches[k][0].tensors) and hasattr(samples.mask, "_ocpg_key")
+        seen.append(tuple(samples.tensors.shape[-2:]))
+    assert seen == [(32, 64), (64, 64), (64, 96)] and pipe is not None
