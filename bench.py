@@ -506,6 +506,9 @@ def main():
         else:
             back_to_eager()
             optimizer = nonlocal_state["optimizer"]
+            if "OCPG_PLANNED_GEMM" not in os.environ:          # same host-cost trade as --eager (above)
+                from ocpg_amd.models.ops.functions import gemm_func
+                gemm_func.PLANNED = False
     if step is None:
         ddp_model = model
         if world > 1:
