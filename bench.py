@@ -462,8 +462,8 @@ def main():
     make_samples, text, targets = synthetic_batch(a.clips_per_gpu, device, seed=42 + rank, roberta=a.text == "roberta")
     step, mode = None, "eager"
     if a.eager and "OCPG_PLANNED_GEMM" not in os.environ:
-        # the eager step is bound by the host: the plan cache's ctypes call costs more host time per GEMM than at::mm, which outweighs
-        # the faster kernels its first-use timing picks (measured: 55.9 ms with, 51 ms without); graph replays have no host cost
+        # the eager step is bound by the host, and with every GEMM routed through the plan cache it is slower (measured: 55.9 ms
+        # against 45.3 ms with at::mm outside the ResNet body); graph replays have no host cost
         from ocpg_amd.models.ops.functions import gemm_func
         gemm_func.PLANNED = False
     if not a.eager:
