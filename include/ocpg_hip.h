@@ -173,7 +173,8 @@ long long ocpg_gemm_plans(void);      /* number of cached plans (diagnostics) */
  * times hipBLASLt's ranked candidates on the caller's operands (eager calls only, never inside a stream capture) and keeps the
  * fastest one whose result agrees with the heuristic's single choice (what at::mm runs) to the rounding of the output type (8e-3 /
  * 1e-3 of max |C| for bf16 / fp16 outputs).  bf16 / fp16 plans only: fp32 plans always keep the heuristic's choice (its ranked fp32
- * list holds kernels that are 2e-3 off).  OCPG_GEMM_TUNE=0 keeps the heuristic's choice everywhere.  ocpg_gemm_tuned returns the number of plans timed on the current device and, in *changed (may be NULL),
+ * list holds kernels that are 2e-3 off).  OCPG_GEMM_TUNE=0 keeps the heuristic's choice everywhere;
+ * OCPG_GEMM_TUNE_FP32=1 (experiment, off by default) also times fp32 plans, validated to 1e-5 of max |C|.  ocpg_gemm_tuned returns the number of plans timed on the current device and, in *changed (may be NULL),
  * how many of them left the first choice; ocpg_gemm_tune_rejected the number of candidates dropped for a differing result. */
 long long ocpg_gemm_tuned(long long* changed);
 long long ocpg_gemm_tune_rejected(void);
