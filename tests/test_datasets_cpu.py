@@ -358,3 +358,27 @@ def test_device_prefetcher_passes_batches_through_in_order():
         assert torch.equal(samples.tensors, batches[k][0].tensors) and hasattr(samples.mask, "_ocpg_key")
         seen.append(tuple(samples.tensors.shape[-2:]))
     assert seen == [(32, 64), (64, 64), (64, 96)] and pipe is not None
+
+
+def test_precision_and_iou_metrics():
+    """ocpg_amd/metrics.py against hand-computed cases of a2d_eval.py:29-67."""
+    from ocpg_amd import metrics
+    gt = torch.zeros(4, 10, 10, dtype=torch.bool)
+    pred = torch.zeros(4, 10, 10, dtype=torch.bool)
+    gt[0, :5] = True; pred[0, :5] = True                     # IoU 1
+    gt[1, :, :6] = True; pred[1, :, 3:9] = True              # I = 30, U = 90 -> 1/3
+    gt[2, :8] = True; pred[2, :6] = True                     # I = 60, U = 80 -> 0.75
+    # instance 3: both empty -> (0 + eps) / (0 + eps) = 1
+    iou, inter, union = metrics.mask_iou(pred, gt)
+    assert torch.allclose(iou, torch.tensor([1.0, 1 / 3, 0.75, 1.0]), atol=1e-6) and inter.tolist() == [50, 30, 60, 0] and union.tolist() == [50, 90, 80, 0]
+    m = metrics.precision_and_iou(pred, gt)
+    assert m["P@0.5"] == 0.75 and m["P@0.7"] == 0.75 and m["P@0.8"] == 0.5 and m["P@0.9"] == 0.5
+    assert abs(m["overall_iou"] - 140 / 220) < 1e-6 and abs(m["mean_iou"] - (1 + 1 / 3 + 0.75 + 1) / 4) < 1e-6
+    # batches of different resolutions accumulate to the same numbers
+    st = metrics.accumulate(None, pred[:2], gt[:2])
+    st = metrics.accumulate(st, torch.nn.functional.pad(pred[2:].float(), (0, 4, 0, 2)).bool(), torch.nn.functional.pad(gt[2:].float(), (0, 4, 0, 2)).bool())
+    assert metrics.summarize(st) == m
+    # the prediction with the highest score is the one evaluated; ties keep the last
+    scores = torch.tensor([[0.1, 0.9, 0.3], [0.5, 0.2, 0.5]])
+    masks = torch.arange(2 * 3).view(2, 3, 1, 1).expand(2, 3, 2, 2)
+    assert metrics.select_best_query(scores, masks)[:, 0, 0].tolist() == [1, 5]
