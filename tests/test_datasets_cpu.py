@@ -382,3 +382,40 @@ def test_precision_and_iou_metrics():
     scores = torch.tensor([[0.1, 0.9, 0.3], [0.5, 0.2, 0.5]])
     masks = torch.arange(2 * 3).view(2, 3, 1, 1).expand(2, 3, 2, 2)
     assert metrics.select_best_query(scores, masks)[:, 0, 0].tolist() == [1, 5]
+
+
+def test_run_length_encoding_and_mask_postprocessing():
+    """models/postprocessors.py: the COCO run-length format by round trip and hand-derived strings; the A2D post-process's un-pad ->
+    resize -> inverted threshold (reference postprocessors.py:36-44) and the score-ordered RefCOCO masks (:124-141)."""
+    import numpy as np
+    from ocpg_amd.models import postprocessors as pp
+    assert pp.rle_counts(np.zeros((2, 2))) == [4] and pp.rle_encode(np.zeros((2, 2)))["counts"] == b"4"
+    assert pp.rle_counts(np.ones((2, 3))) == [0, 6] and pp.rle_encode(np.ones((2, 3)))["counts"] == b"06"
+    m = np.array([[0, 1, 1], [0, 0, 1]], dtype=np.uint8)                          # column-major: 0 0 | 1 | 0 | 1 1
+    assert pp.rle_counts(m) == [2, 1, 1, 2]
+    assert pp.rle_encode(m)["counts"] == bytes([48 + 2, 48 + 1, 48 + 1, 48 + 1])   # the 4th count is stored as 2 - counts[1] = 1
+    assert pp.rle_encode(np.zeros((40, 40)))["counts"] == bytes([48 + (1600 & 31) + 32, 48 + ((1600 >> 5) & 31) + 32, 48 + (1600 >> 10)])
+    g = np.random.default_rng(0)
+    for shape in ((1, 1), (7, 5), (64, 48), (33, 200)):
+        for p in (0.02, 0.5, 0.97):
+            x = (g.random(shape) < p).astype(np.uint8)
+            r = pp.rle_encode(torch.from_numpy(x))
+            assert r["size"] == list(shape) and np.array_equal(pp.rle_decode(r), x)
+    blob = np.zeros((120, 90), dtype=np.uint8)
+    blob[30:90, 20:70] = 1                                                         # long equal runs: negative deltas in the string
+    assert np.array_equal(pp.rle_decode(pp.rle_encode(blob)), blob)
+    # A2D: logits positive in the top-left quadrant of the un-padded region -> the INVERTED mask is False exactly there
+    logits = torch.full((1, 1, 2, 16, 24), -8.0)
+    logits[0, 0, 0, :6, :10] = 8.0
+    out = {"pred_logits": torch.tensor([[[[2.0], [-1.0]]]]), "pred_masks": logits}
+    res = pp.A2DSentencesPostProcess()(out, torch.tensor([[24, 40]]), torch.tensor([[12, 20]]))
+    assert torch.allclose(res[0]["scores"], torch.tensor([2.0, -1.0]).sigmoid()) and res[0]["masks"].shape == (2, 1, 24, 40)
+    assert not res[0]["masks"][0, 0, :11, :19].any() and res[0]["masks"][0, 0, 13:, :].all() and res[0]["masks"][1].all()
+    assert np.array_equal(pp.rle_decode(res[0]["rle_masks"][0]), res[0]["masks"][0, 0].numpy().astype(np.uint8))
+    # RefCOCO: masks come back ordered by descending score
+    out2 = {"pred_logits": torch.tensor([[[[-1.0], [3.0]]]]), "pred_masks": logits, "pred_boxes": torch.rand(1, 1, 2, 4)}
+    r2 = pp.PostProcessSegm()([{}], out2, torch.tensor([[16, 24]]), torch.tensor([[16, 24]]))
+    assert r2[0]["masks"].shape == (2, 1, 16, 24) and int(r2[0]["masks"][0].sum()) == 0 and int(r2[0]["masks"][1].sum()) == 60
+    import argparse
+    assert isinstance(pp.build_postprocessors(argparse.Namespace(threshold=0.5, masks=True), "a2d"), pp.A2DSentencesPostProcess)
+    assert set(pp.build_postprocessors(argparse.Namespace(threshold=0.5, masks=True), "ytvos")) == {"bbox", "segm"}
