@@ -127,3 +127,37 @@ def train_one_epoch(model, criterion, data_loader, optimizer, device, max_norm=0
         loss, _, norm = train_step(model, criterion, samples, captions, targets, optimizer, max_norm, amp_dtype, grad_scaler)
         history.append((loss, float(norm)))
     return history
+
+
+@torch.no_grad()
+def evaluate_referred_masks(model, data_loader, postprocessor, device, amp_dtype=None):
+    """The A2D-Sentences / JHMDB-Sentences evaluation loop (reference engine.py:126-194) up to the metrics that need no COCO api:
+    per sample the post-processed mask of the highest-scoring query against the ground-truth mask of the annotated frame at the
+    original resolution -> precision@K, overall IoU, mean IoU (ocpg_amd/metrics.py).  Targets carry `orig_size`, `size` and the
+    ground truth as `gt_mask` [H0, W0] (the reference reads it from the dataset's COCO-format annotation file instead).  With a
+    process group the running sums are all-reduced, so every rank returns the same numbers."""
+    from . import metrics
+    from .util.misc import targets_to
+    model.eval()
+    state = None
+    for samples, targets in data_loader:
+        samples = samples.to(device)
+        captions = [t["caption"] for t in targets]
+        targets = targets_to(targets, device)
+        with torch.autocast(device_type=torch.device(device).type, dtype=amp_dtype, enabled=amp_dtype is not None):
+            outputs = model(samples, captions, targets)
+        orig = torch.stack([t["orig_size"] for t in targets], dim=0)
+        size = torch.stack([t["size"] for t in targets], dim=0)
+        for p, t in zip(postprocessor(outputs, orig, size), targets):
+            best = metrics.select_best_query(p["scores"][None], p["masks"][None, :, 0])      # [1, H0, W0]
+            state = metrics.accumulate(state, best, t["gt_mask"][None].bool())
+    if state is None:
+        return {}
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        ious = torch.cat(state[0])
+        gathered = [None] * dist.get_world_size()
+        dist.all_gather_object(gathered, ious.cpu())
+        sums = torch.stack([state[1], state[2]]).to(torch.float64)
+        dist.all_reduce(sums)
+        state = ([g.to(ious.device) for g in gathered], sums[0].float(), sums[1].float())
+    return metrics.summarize(state)

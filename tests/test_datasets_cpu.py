@@ -419,3 +419,29 @@ def test_run_length_encoding_and_mask_postprocessing():
     import argparse
     assert isinstance(pp.build_postprocessors(argparse.Namespace(threshold=0.5, masks=True), "a2d"), pp.A2DSentencesPostProcess)
     assert set(pp.build_postprocessors(argparse.Namespace(threshold=0.5, masks=True), "ytvos")) == {"bbox", "segm"}
+
+
+def test_evaluation_loop_with_a_stand_in_model():
+    """engine.evaluate_referred_masks (reference engine.py:126-194 + a2d_eval.py:37-67): post-process -> best query -> metrics."""
+    from ocpg_amd import engine
+    from ocpg_amd.models.postprocessors import A2DSentencesPostProcess
+    from ocpg_amd.util.misc import NestedTensor
+
+    class Stub(torch.nn.Module):
+        def forward(self, samples, captions, targets):
+            b = samples.tensors.shape[0]
+            masks = torch.full((b, 1, 2, 16, 24), 8.0)                 # the A2D post-process inverts: positive logits = background
+            masks[:, 0, 1, :8, :12] = -8.0                              # query 1 segments the top-left quarter of the un-padded 16 x 24
+            masks[:, 0, 0, :, :] = -8.0                                 # query 0 segments everything
+            logits = torch.tensor([[-2.0], [2.0]]).expand(b, 1, 2, 1)   # query 1 scores highest
+            return {"pred_logits": logits, "pred_masks": masks}
+
+    def batch(gt_rows):
+        gt = torch.zeros(32, 48, dtype=torch.bool)
+        gt[:gt_rows, :24] = True
+        t = {"caption": "x", "orig_size": torch.tensor([32, 48]), "size": torch.tensor([16, 24]), "gt_mask": gt}
+        return NestedTensor(torch.zeros(1, 1, 3, 16, 24), torch.zeros(1, 1, 16, 24, dtype=torch.bool)), [t]
+    # prediction = rows < 16, cols < 24 at 32 x 48; ground truths: identical (IoU 1) and half of it (IoU 0.5, not > 0.5)
+    m = engine.evaluate_referred_masks(Stub(), [batch(16), batch(8)], A2DSentencesPostProcess(), "cpu")
+    assert m["P@0.5"] == 0.5 and m["P@0.9"] == 0.5 and abs(m["mean_iou"] - 0.75) < 1e-6
+    assert abs(m["overall_iou"] - (384 + 192) / (384 + 384)) < 1e-6
