@@ -2,9 +2,11 @@
 # A/B battery to run FIRST next round (one gpurun call, ~8 GPU-minutes): settles what this round left open.
 #   1. eager step with / without the plan cache on the non-ResNet GEMMs, same box (the 55.9 vs 45.3 ms question)
 #   2. graph step with candidate timing off / on / on incl. fp32 plans (validated to 1e-5)
+#   3. weight gradients as ONE GEMM each (OCPG_SPLIT_K=0): with candidate timing hipBLASLt's own split-K kernels may beat the
+#      row-split batched GEMM + sum (82 reductions per step)
 # Output: gpurun_out/ab/*.json (bench lines) and a one-line summary per run.
 O=gpurun_out/ab; mkdir -p $O
 run() { tag=$1; shift; env "$@" timeout -k 10 240 python bench.py --no-cpu-baseline --no-kernel-timing --steps 12 --warmup 4 ${EXTRA} > $O/$tag.json 2> $O/$tag.err || { tail -3 $O/$tag.err; return 1; }
         python3 -c "import json,sys; d=json.loads(open('$O/$tag.json').read().strip().splitlines()[-1]); print('$tag', round(d['ms_per_step'],2), 'ms', d.get('gemm_plans'))"; }
 EXTRA=--eager run eager_planned OCPG_PLANNED_GEMM=1 && EXTRA=--eager run eager_atmm OCPG_PLANNED_GEMM=0 && \
-EXTRA= run graph_tune_off OCPG_GEMM_TUNE=0 && EXTRA= run graph_tune_on OCPG_GEMM_TUNE=1 && EXTRA= run graph_tune_fp32 OCPG_GEMM_TUNE_FP32=1
+EXTRA= run graph_tune_off OCPG_GEMM_TUNE=0 && EXTRA= run graph_tune_on OCPG_GEMM_TUNE=1 && EXTRA= run graph_tune_fp32 OCPG_GEMM_TUNE_FP32=1 && EXTRA= run graph_no_manual_splitk OCPG_SPLIT_K=0
