@@ -185,6 +185,8 @@ class GraphStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         optimizer.zero_grad(set_to_none=True)
+        from ocpg_amd.models.ops.functions.fused_ln_func import GraphRng
+        self.rng = GraphRng(self.x.device)                      # dropout generator state of this capture (device-resident base)
         self.graph = torch.cuda.CUDAGraph(keep_graph=True)      # instantiated below, after the memset nodes are repaired
         # The captured step's outputs (model outputs, the 36 losses) stay referenced for the lifetime of the graph (static
         # outputs); self.check() compares a replay against an eager step before the timed region.
@@ -192,9 +194,11 @@ class GraphStep:
         # capture on the warm-up stream: the library's hipBLASLt workspace is per (device, stream) and was allocated there
         # (a hipMalloc inside the capture would invalidate it)
         # N > 1: RCCL's watchdog thread may poll events while we capture; only THIS thread's unsafe calls should invalidate the capture
-        with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local" if world > 1 else "global"):
+        with self.rng, torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local" if world > 1 else "global"):
             self.loss = forward_backward(model, criterion, NestedTensor(self.x.clone(), self._mask()), text, targets, amp_dtype,
                                          self.num_boxes, keep=self.static, scaler=self.scaler)
+            self.rng.advance()          # last node of the step: the next replay draws fresh dropout masks
+        self.rng.finalize()
         # memset nodes (torch's reduction semaphores) replay with a corrupted pattern on this ROCm: swap them for kernel nodes
         import ctypes
         from ocpg_amd import _lib
@@ -229,6 +233,7 @@ class GraphStep:
         """One replay (no optimizer step) against the eager loss of the warm-up steps: finite, same ballpark (dropout
         masks differ), every gradient finite."""
         self.graph.replay()
+        self.rng.replayed()
         torch.cuda.synchronize()
         loss = float(self.loss)
         # (fp16: a replay at the initial loss scale may overflow -- that is the scaler's business, not a capture failure)
@@ -248,6 +253,7 @@ class GraphStep:
         if self.fence:
             torch.cuda.synchronize()
         self.graph.replay()
+        self.rng.replayed()
         if self.fence:
             torch.cuda.synchronize()
         self.criterion.iter_device += self.calls_per_fwd
@@ -445,7 +451,7 @@ def main():
     from ocpg_amd.models import build_model
     from ocpg_amd.models.ops.functions import ms_deform_attn_func as msda_fn
 
-    torch.manual_seed(42 + rank)
+    torch.manual_seed(42)           # replicas start from the SAME weights (the graph step only all-reduces gradients) ...
     torch.backends.cudnn.benchmark = True
     if os.environ.get("OCPG_BLAS"):          # A/B: 'hipblas' (rocBLAS) | 'hipblaslt'
         torch.backends.cuda.preferred_blas_library(os.environ["OCPG_BLAS"])
@@ -457,6 +463,11 @@ def main():
             m.to(memory_format=torch.channels_last)
     criterion.to(device)
     model.train(), criterion.train()
+    if world > 1:                   # ... and by construction: rank 0's parameters and buffers everywhere (what DDP's constructor does)
+        with torch.no_grad():
+            for t in list(model.parameters()) + list(model.buffers()):
+                dist.broadcast(t, src=0)
+    torch.manual_seed(42 + rank)    # per-rank stream for data and dropout only (main.py:44-45)
     optimizer = make_optimizer(model, args)
     amp_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}[a.dtype]
     make_samples, text, targets = synthetic_batch(a.clips_per_gpu, device, seed=42 + rank, roberta=a.text == "roberta")
@@ -499,9 +510,25 @@ def main():
                 print("[bench] another rank could not capture: running eagerly on all ranks", file=sys.stderr, flush=True)
                 ok, step = 0, None
         if ok:
-            for _ in range(3):      # the round-1 instability showed after optimizer steps: exercise them before the timed region
-                if not bool(torch.isfinite(step())) and amp_dtype != torch.float16:       # fp16: overflowed steps are the scaler's to skip
-                    raise RuntimeError("graph replay turned non-finite after an optimizer step")
+            # the round-1 instability showed after optimizer steps: exercise them before the timed region.  The steps contain the
+            # gradient all-reduce, so every rank runs all three; the verdict is then agreed on with a MIN all-reduce (a rank-local
+            # raise here would leave the other ranks blocked in the next collective until the RCCL timeout)
+            finite = 1
+            try:
+                for _ in range(3):
+                    if not bool(torch.isfinite(step())) and amp_dtype != torch.float16:   # fp16: overflowed steps are the scaler's to skip
+                        finite = 0
+            except Exception as e:
+                print(f"[bench] graph step failed ({type(e).__name__}: {str(e)[:200]})", file=sys.stderr, flush=True)
+                finite = 0
+            if world > 1:
+                flag = torch.tensor([finite], dtype=torch.int32, device=device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                finite = int(flag.item())
+            if not finite:
+                print("[bench] graph replay turned non-finite after an optimizer step (on some rank): running eagerly", file=sys.stderr, flush=True)
+                ok, step = 0, None
+        if ok:
             mode = "hipgraph(fwd+criterion+bwd)"
         else:
             back_to_eager()

@@ -219,20 +219,23 @@ int ocpg_matcher_cost_f32(const float* logits, const float* boxes, const float* 
 /* Transformer-layer glue (models/deformable_transformer.py:236-257,313-336), one HBM pass each way:
  *   y = LayerNorm(res + dropout(x)):  x [R,C] (x_dtype 0 fp32 / 1 bf16), res / y fp32, C % 4 == 0, C <= 2048; mean, rstd [R]
  *     are kept for the backward, which recomputes the dropout mask from (seed, offset) (Philox-4x32-10, counter = element/4);
+ *     rng_base: NULL, or a DEVICE pointer to one 64-bit word that the kernel adds to `offset` when it runs -- a call captured
+ *     into a HIP graph bakes `offset` into the node, so the caller keeps the per-step base in device memory and advances it
+ *     between replays (every replay then draws fresh masks, as models/deformable_transformer.py:236-257 does every step);
  *     bwd: gx (x's dtype, may be NULL), gres (may be NULL) fully written; dgb_part [slots, 2, C] partial (dgamma, dbeta) sums,
  *     fully written, slots = ocpg_dropout_add_ln_bwd_slots(R); the caller sums over the slots.
  *   h = dropout(relu(a + bias)):  a, bias, h share dtype (0 fp32 / 1 bf16), h may alias a; bwd from h only:
  *     ga = gh / (1-p) where h > 0; dbias_part [slots, C] fp32 partial column sums, fully written, slots =
  *     ocpg_bias_relu_dropout_bwd_slots(R, C, dtype); the caller sums over the slots. */
 int ocpg_dropout_add_ln_fwd(const void* x, const float* res, const float* gamma, const float* beta, long long R, int C, float eps, float p,
-                            unsigned long long seed, unsigned long long offset, int x_dtype, float* y, float* mean, float* rstd,
-                            void* stream);
+                            unsigned long long seed, unsigned long long offset, const unsigned long long* rng_base, int x_dtype, float* y,
+                            float* mean, float* rstd, void* stream);
 int ocpg_dropout_add_ln_bwd(const float* gy, const void* x, const float* res, const float* gamma, const float* mean, const float* rstd,
-                            long long R, int C, float p, unsigned long long seed, unsigned long long offset, int x_dtype, void* gx, float* gres,
-                            float* dgb_part, void* stream);
+                            long long R, int C, float p, unsigned long long seed, unsigned long long offset, const unsigned long long* rng_base,
+                            int x_dtype, void* gx, float* gres, float* dgb_part, void* stream);
 long long ocpg_dropout_add_ln_bwd_slots(long long R);
 int ocpg_bias_relu_dropout_fwd(const void* a, const void* bias, long long R, int C, float p, unsigned long long seed,
-                               unsigned long long offset, int dtype, void* h, void* stream);
+                               unsigned long long offset, const unsigned long long* rng_base, int dtype, void* h, void* stream);
 int ocpg_bias_relu_dropout_bwd(const void* gh, const void* h, long long R, int C, float p, int dtype, void* ga, float* dbias_part,
                                void* stream);
 long long ocpg_bias_relu_dropout_bwd_slots(long long R, int C, int dtype);
@@ -288,12 +291,12 @@ int ocpg_masked_ce_bwd_f32(const float* x, const float* w, const float* t, const
  * Returns -2000 when the shape is not served (the caller keeps its generic attention path). */
 int ocpg_attn_smallk_fwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv,
                          const unsigned char* key_pad, float scale, int Lq, int B, int H, int hd, int Lk, float pdrop,
-                         unsigned long long seed, unsigned long long offset, void* out, long long ldo, float* lse, int dtype,
-                         void* stream);
+                         unsigned long long seed, unsigned long long offset, const unsigned long long* rng_base, void* out,
+                         long long ldo, float* lse, int dtype, void* stream);
 int ocpg_attn_smallk_bwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv,
                          const unsigned char* key_pad, const void* dout, long long ldo, const float* lse, float scale, int Lq,
-                         int B, int H, int hd, int Lk, float pdrop, unsigned long long seed, unsigned long long offset, void* dq,
-                         long long lddq, float* dk, float* dv, int dtype, void* stream);
+                         int B, int H, int hd, int Lk, float pdrop, unsigned long long seed, unsigned long long offset,
+                         const unsigned long long* rng_base, void* dq, long long lddq, float* dk, float* dv, int dtype, void* stream);
 
 /* LFM coefficient branch (models/modules.py:17-19,36-39: `self.fc(self.pool(self.laplace(x)))` with laplace a 3x3 VALID conv): the
  * spatial mean of a convolution is linear in the input, mean conv(x)[co] = b[co] + sum w[co,ci,ky,kx] m[ci,ky,kx] with m the mean

@@ -56,11 +56,11 @@ SIGNATURES = {
     "ocpg_proj_fwd_f32": [_vp] * 5 + [_int] * 5 + [_vp] * 5,
     "ocpg_proj_bwd_f32": [_vp] * 9 + [_int] * 5 + [_vp] * 4,
     "ocpg_matcher_cost_f32": [_vp] * 3 + [ctypes.c_longlong] * 4 + [_vp] * 4 + [_int] * 7 + [ctypes.c_float] * 5 + [_vp] * 4,
-    "ocpg_dropout_add_ln_fwd": [_vp] * 4 + [ctypes.c_longlong, _int, ctypes.c_float, ctypes.c_float, ctypes.c_ulonglong, ctypes.c_ulonglong, _int]
+    "ocpg_dropout_add_ln_fwd": [_vp] * 4 + [ctypes.c_longlong, _int, ctypes.c_float, ctypes.c_float, ctypes.c_ulonglong, ctypes.c_ulonglong, _vp, _int]
                                + [_vp] * 4,
-    "ocpg_dropout_add_ln_bwd": [_vp] * 6 + [ctypes.c_longlong, _int, ctypes.c_float, ctypes.c_ulonglong, ctypes.c_ulonglong, _int] + [_vp] * 4,
+    "ocpg_dropout_add_ln_bwd": [_vp] * 6 + [ctypes.c_longlong, _int, ctypes.c_float, ctypes.c_ulonglong, ctypes.c_ulonglong, _vp, _int] + [_vp] * 4,
     "ocpg_dropout_add_ln_bwd_slots": [ctypes.c_longlong],
-    "ocpg_bias_relu_dropout_fwd": [_vp, _vp, ctypes.c_longlong, _int, ctypes.c_float, ctypes.c_ulonglong, ctypes.c_ulonglong, _int, _vp, _vp],
+    "ocpg_bias_relu_dropout_fwd": [_vp, _vp, ctypes.c_longlong, _int, ctypes.c_float, ctypes.c_ulonglong, ctypes.c_ulonglong, _vp, _int, _vp, _vp],
     "ocpg_bias_relu_dropout_bwd": [_vp, _vp, ctypes.c_longlong, _int, ctypes.c_float, _int, _vp, _vp, _vp],
     "ocpg_bias_relu_dropout_bwd_slots": [ctypes.c_longlong, _int, _int],
     "ocpg_multi_cast": [_vp] * 4 + [_int, ctypes.c_longlong, _int, _int, _vp],
@@ -75,9 +75,9 @@ SIGNATURES = {
     "ocpg_im2col3x3_nhwc": [_vp] + [_int] * 6 + [_vp, _int, _vp],
     "ocpg_col2im3x3_nhwc": [_vp] + [_int] * 6 + [_vp, _int, _vp],
     "ocpg_attn_smallk_fwd": [_vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, ctypes.c_float] + [_int] * 5
-                            + [ctypes.c_float, ctypes.c_ulonglong, ctypes.c_ulonglong, _vp, ctypes.c_longlong, _vp, _int, _vp],
+                            + [ctypes.c_float, ctypes.c_ulonglong, ctypes.c_ulonglong, _vp, _vp, ctypes.c_longlong, _vp, _int, _vp],
     "ocpg_attn_smallk_bwd": [_vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, _vp, ctypes.c_longlong, _vp,
-                             ctypes.c_float] + [_int] * 5 + [ctypes.c_float, ctypes.c_ulonglong, ctypes.c_ulonglong, _vp, ctypes.c_longlong,
+                             ctypes.c_float] + [_int] * 5 + [ctypes.c_float, ctypes.c_ulonglong, ctypes.c_ulonglong, _vp, _vp, ctypes.c_longlong,
                                                              _vp, _vp, _int, _vp],
     "ocpg_win_attn_fwd": [_vp, _vp, _vp, ctypes.c_float] + [_int] * 5 + [_vp, _vp, _int, _vp],
     "ocpg_win_attn_bwd": [_vp, _vp, _vp, _vp, ctypes.c_float] + [_int] * 5 + [_vp] * 6 + [_int, _vp],
@@ -114,6 +114,18 @@ def collect_kernel_timing(work=None):
     return out
 
 
+# ---- optional call census (tests: prove WHICH entry points served a module; bench.py: launches per step by symbol) ----
+CENSUS = {"on": False, "calls": {}}
+
+
+def census(on=True):
+    """Start (and clear) / stop counting successful (rc == 0) calls per entry point; read CENSUS['calls']."""
+    CENSUS["on"] = on
+    if on:
+        CENSUS["calls"] = {}
+    return CENSUS["calls"]
+
+
 class _Lib:
     """Attribute proxy over the CDLL: every kernel entry point can be bracketed by events when timing is on."""
 
@@ -122,12 +134,18 @@ class _Lib:
 
     def __getattr__(self, name):
         fn = getattr(self._cdll, name)
-        if name not in SIGNATURES or name in _UNTIMED or name.startswith("ocpg_msda_"):
+        if name not in SIGNATURES or name in _UNTIMED:
             setattr(self, name, fn)
             return fn
+        timed = not name.startswith("ocpg_msda_")       # MSDeformAttn is timed by its own wrapper (knows enc / dec shape)
 
         def call(*a):
-            if not _TIMING["on"]:
+            if CENSUS["on"]:
+                rc = fn(*a)
+                if rc == 0:
+                    CENSUS["calls"][name] = CENSUS["calls"].get(name, 0) + 1
+                return rc
+            if not (timed and _TIMING["on"]):
                 return fn(*a)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

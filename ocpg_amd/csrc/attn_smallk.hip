@@ -77,7 +77,9 @@ template <typename T>
 __global__ __launch_bounds__(NT) void attn_smallk_fwd(const T* __restrict__ q, long long ldq, const T* __restrict__ k, long long ldk,
                                                       const T* __restrict__ v, long long ldv, const unsigned char* __restrict__ pad,
                                                       float scale, int Lq, int B, int H, int Lk, float pdrop, uint64_t seed,
-                                                      uint64_t offset, T* __restrict__ out, long long ldo, float* __restrict__ lse) {
+                                                      uint64_t offset0, const uint64_t* __restrict__ rng_base, T* __restrict__ out,
+                                                      long long ldo, float* __restrict__ lse) {
+  const uint64_t offset = offset0 + (rng_base ? *rng_base : 0ull);      // graph replays: the step's base lives in device memory
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* ks = smem;
   float* vs = ks + Lk * H * HS;
@@ -134,9 +136,10 @@ template <typename T, int LKP>
 __global__ __launch_bounds__(NT) void attn_smallk_bwd(const T* __restrict__ q, long long ldq, const T* __restrict__ k, long long ldk,
                                                       const T* __restrict__ v, long long ldv, const unsigned char* __restrict__ pad,
                                                       const T* __restrict__ dout, long long ldo, const float* __restrict__ lse, float scale,
-                                                      int Lq, int B, int H, int Lk, float pdrop, uint64_t seed, uint64_t offset,
-                                                      int groups_per_block, T* __restrict__ dq, long long lddq, float* __restrict__ dk,
-                                                      float* __restrict__ dv) {
+                                                      int Lq, int B, int H, int Lk, float pdrop, uint64_t seed, uint64_t offset0,
+                                                      const uint64_t* __restrict__ rng_base, int groups_per_block, T* __restrict__ dq,
+                                                      long long lddq, float* __restrict__ dk, float* __restrict__ dv) {
+  const uint64_t offset = offset0 + (rng_base ? *rng_base : 0ull);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tok_per = NT / H;
   float* ks = smem;
@@ -259,8 +262,8 @@ inline int check_dims(int Lq, int B, int H, int hd, int Lk) {
 
 extern "C" int ocpg_attn_smallk_fwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv,
                                     const unsigned char* key_pad, float scale, int Lq, int B, int H, int hd, int Lk, float pdrop,
-                                    unsigned long long seed, unsigned long long offset, void* out, long long ldo, float* lse, int dtype,
-                                    void* stream) {
+                                    unsigned long long seed, unsigned long long offset, const unsigned long long* rng_base, void* out,
+                                    long long ldo, float* lse, int dtype, void* stream) {
   if (int e = check_dims(Lq, B, H, hd, Lk)) return e;
   if (Lq == 0 || B == 0) return 0;
   if (!q) return -1001;
@@ -275,13 +278,14 @@ extern "C" int ocpg_attn_smallk_fwd(const void* q, long long ldq, const void* k,
   hipStream_t st = (hipStream_t)stream;
   if (dtype == 0)
     attn_smallk_fwd<float><<<grid, NT, lds, st>>>((const float*)q, ldq, (const float*)k, ldk, (const float*)v, ldv, key_pad, scale, Lq, B, H, Lk,
-                                                  pdrop, seed, offset, (float*)out, ldo, lse);
+                                                  pdrop, seed, offset, (const uint64_t*)rng_base, (float*)out, ldo, lse);
   else if (dtype == 1)
     attn_smallk_fwd<__hip_bfloat16><<<grid, NT, lds, st>>>((const __hip_bfloat16*)q, ldq, (const __hip_bfloat16*)k, ldk, (const __hip_bfloat16*)v,
-                                                           ldv, key_pad, scale, Lq, B, H, Lk, pdrop, seed, offset, (__hip_bfloat16*)out, ldo, lse);
+                                                           ldv, key_pad, scale, Lq, B, H, Lk, pdrop, seed, offset, (const uint64_t*)rng_base,
+                                                           (__hip_bfloat16*)out, ldo, lse);
   else
     attn_smallk_fwd<__half><<<grid, NT, lds, st>>>((const __half*)q, ldq, (const __half*)k, ldk, (const __half*)v, ldv, key_pad, scale, Lq, B, H,
-                                                   Lk, pdrop, seed, offset, (__half*)out, ldo, lse);
+                                                   Lk, pdrop, seed, offset, (const uint64_t*)rng_base, (__half*)out, ldo, lse);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
@@ -295,7 +299,7 @@ inline void allow_lds(K kernel, size_t bytes) {
 #define BWD_LAUNCH(T_, LKP_)                                                                                                         \
   allow_lds(attn_smallk_bwd<T_, LKP_>, lds);                                                                                         \
   attn_smallk_bwd<T_, LKP_><<<grid, NT, lds, st>>>((const T_*)q, ldq, (const T_*)k, ldk, (const T_*)v, ldv, key_pad, (const T_*)dout, ldo, lse, \
-                                                   scale, Lq, B, H, Lk, pdrop, seed, offset, gpb, (T_*)dq, lddq, dk, dv)
+                                                   scale, Lq, B, H, Lk, pdrop, seed, offset, (const uint64_t*)rng_base, gpb, (T_*)dq, lddq, dk, dv)
 #define BWD_DISPATCH(T_)                           \
   if (Lk <= 8) { BWD_LAUNCH(T_, 8); }              \
   else if (Lk <= 16) { BWD_LAUNCH(T_, 16); }       \
@@ -303,8 +307,9 @@ inline void allow_lds(K kernel, size_t bytes) {
 
 extern "C" int ocpg_attn_smallk_bwd(const void* q, long long ldq, const void* k, long long ldk, const void* v, long long ldv,
                                     const unsigned char* key_pad, const void* dout, long long ldo, const float* lse, float scale, int Lq,
-                                    int B, int H, int hd, int Lk, float pdrop, unsigned long long seed, unsigned long long offset, void* dq,
-                                    long long lddq, float* dk, float* dv, int dtype, void* stream) {
+                                    int B, int H, int hd, int Lk, float pdrop, unsigned long long seed, unsigned long long offset,
+                                    const unsigned long long* rng_base, void* dq, long long lddq, float* dk, float* dv, int dtype,
+                                    void* stream) {
   if (int e = check_dims(Lq, B, H, hd, Lk)) return e;
   if (Lq == 0 || B == 0) return 0;
   if (!q) return -1001;

@@ -64,8 +64,9 @@ constexpr int NCH_MAX = 8;      // float4 chunks per lane: C <= 64 * 4 * NCH_MAX
 template <typename XT, int NCH>
 __global__ __launch_bounds__(256) void dal_fwd(const XT* __restrict__ x, const float* __restrict__ res, const float* __restrict__ gamma,
                                                const float* __restrict__ beta, long long R, int C, float eps, uint32_t thr, float scale,
-                                               uint64_t seed, uint64_t offset, float* __restrict__ y, float* __restrict__ mean,
-                                               float* __restrict__ rstd) {
+                                               uint64_t seed, uint64_t offset0, const uint64_t* __restrict__ rng_base,
+                                               float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd) {
+  const uint64_t offset = offset0 + (rng_base ? *rng_base : 0ull);      // graph replays: the step's base lives in device memory
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= R) return;
   const int lane = threadIdx.x & 63;
@@ -112,7 +113,9 @@ template <typename XT, int NCH>
 __global__ __launch_bounds__(256) void dal_bwd(const float* __restrict__ gy, const XT* __restrict__ x, const float* __restrict__ res,
                                                const float* __restrict__ gamma, const float* __restrict__ mean,
                                                const float* __restrict__ rstd, long long R, int C, uint32_t thr, float scale, uint64_t seed,
-                                               uint64_t offset, XT* __restrict__ gx, float* __restrict__ gres, float* __restrict__ dgamma) {
+                                               uint64_t offset0, const uint64_t* __restrict__ rng_base, XT* __restrict__ gx,
+                                               float* __restrict__ gres, float* __restrict__ dgamma) {
+  const uint64_t offset = offset0 + (rng_base ? *rng_base : 0ull);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = C / 4;
   float dg[NCH][4], db[NCH][4], g[NCH][4];
@@ -213,7 +216,9 @@ template <> struct Wide<__hip_bfloat16, 2> {
 // h = dropout(relu(a + bias)) ; lane = 4*V consecutive columns (the generator's counter stays "element index / 4")
 template <typename T, int V>
 __global__ __launch_bounds__(256) void brd_fwd(const T* __restrict__ a, const T* __restrict__ bias, long long totalv, int C, uint32_t thr,
-                                               float scale, uint64_t seed, uint64_t offset, T* __restrict__ h) {
+                                               float scale, uint64_t seed, uint64_t offset0, const uint64_t* __restrict__ rng_base,
+                                               T* __restrict__ h) {
+  const uint64_t offset = offset0 + (rng_base ? *rng_base : 0ull);
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < totalv; i += (long long)gridDim.x * 256) {
     const int col = (int)((i * 4 * V) % C);
     float av[V][4], bv[V][4], o[V][4];
@@ -276,8 +281,8 @@ inline uint32_t threshold(float p) {
 extern "C" {
 
 int ocpg_dropout_add_ln_fwd(const void* x, const float* res, const float* gamma, const float* beta, long long R, int C, float eps, float p,
-                            unsigned long long seed, unsigned long long offset, int x_dtype, float* y, float* mean, float* rstd,
-                            void* stream) {
+                            unsigned long long seed, unsigned long long offset, const unsigned long long* rng_base, int x_dtype, float* y,
+                            float* mean, float* rstd, void* stream) {
   if (R < 0 || C <= 0 || C % 4 != 0 || C > 64 * 4 * NCH_MAX) return -1006;
   if (p < 0.f || p >= 1.f) return -1007;
   if (R == 0) return 0;
@@ -289,7 +294,7 @@ int ocpg_dropout_add_ln_fwd(const void* x, const float* res, const float* gamma,
   hipStream_t st = (hipStream_t)stream;
   if (x_dtype != 0 && x_dtype != 1) return -1008;
   const int nc = (C + 255) / 256;
-#define DAL_FWD(XT_, N_) dal_fwd<XT_, N_><<<grid, 256, 0, st>>>((const XT_*)x, res, gamma, beta, R, C, eps, thr, scale, seed, offset, y, mean, rstd)
+#define DAL_FWD(XT_, N_) dal_fwd<XT_, N_><<<grid, 256, 0, st>>>((const XT_*)x, res, gamma, beta, R, C, eps, thr, scale, seed, offset, (const uint64_t*)rng_base, y, mean, rstd)
 #define DAL_FWD_T(XT_) do { if (nc <= 1) DAL_FWD(XT_, 1); else if (nc <= 2) DAL_FWD(XT_, 2); else if (nc <= 4) DAL_FWD(XT_, 4); else DAL_FWD(XT_, 8); } while (0)
   if (x_dtype == 0) DAL_FWD_T(float); else DAL_FWD_T(__hip_bfloat16);
   const hipError_t e = hipGetLastError();
@@ -302,8 +307,8 @@ long long ocpg_dropout_add_ln_bwd_slots(long long R) {
 }
 
 int ocpg_dropout_add_ln_bwd(const float* gy, const void* x, const float* res, const float* gamma, const float* mean, const float* rstd,
-                            long long R, int C, float p, unsigned long long seed, unsigned long long offset, int x_dtype, void* gx, float* gres,
-                            float* dgb_part, void* stream) {
+                            long long R, int C, float p, unsigned long long seed, unsigned long long offset, const unsigned long long* rng_base,
+                            int x_dtype, void* gx, float* gres, float* dgb_part, void* stream) {
   if (R < 0 || C <= 0 || C % 4 != 0 || C > 64 * 4 * NCH_MAX) return -1006;
   if (p < 0.f || p >= 1.f) return -1007;
   if (R == 0) return 0;
@@ -315,7 +320,7 @@ int ocpg_dropout_add_ln_bwd(const float* gy, const void* x, const float* res, co
   hipStream_t st = (hipStream_t)stream;
   if (x_dtype != 0 && x_dtype != 1) return -1008;
   const int nc = (C + 255) / 256;
-#define DAL_BWD(XT_, N_) dal_bwd<XT_, N_><<<grid, 256, 0, st>>>(gy, (const XT_*)x, res, gamma, mean, rstd, R, C, thr, scale, seed, offset, (XT_*)gx, gres, dgb_part)
+#define DAL_BWD(XT_, N_) dal_bwd<XT_, N_><<<grid, 256, 0, st>>>(gy, (const XT_*)x, res, gamma, mean, rstd, R, C, thr, scale, seed, offset, (const uint64_t*)rng_base, (XT_*)gx, gres, dgb_part)
 #define DAL_BWD_T(XT_) do { if (nc <= 1) DAL_BWD(XT_, 1); else if (nc <= 2) DAL_BWD(XT_, 2); else if (nc <= 4) DAL_BWD(XT_, 4); else DAL_BWD(XT_, 8); } while (0)
   if (x_dtype == 0) DAL_BWD_T(float); else DAL_BWD_T(__hip_bfloat16);
   const hipError_t e = hipGetLastError();
@@ -323,7 +328,7 @@ int ocpg_dropout_add_ln_bwd(const float* gy, const void* x, const float* res, co
 }
 
 int ocpg_bias_relu_dropout_fwd(const void* a, const void* bias, long long R, int C, float p, unsigned long long seed,
-                               unsigned long long offset, int dtype, void* h, void* stream) {
+                               unsigned long long offset, const unsigned long long* rng_base, int dtype, void* h, void* stream) {
   if (R < 0 || C <= 0 || C % 4 != 0) return -1006;
   if (p < 0.f || p >= 1.f) return -1007;
   if (R == 0) return 0;
@@ -336,9 +341,9 @@ int ocpg_bias_relu_dropout_fwd(const void* a, const void* bias, long long R, int
   const long long want = (totalv + 255) / 256;
   const unsigned grid = (unsigned)(want < 256 * 32 ? want : 256 * 32);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == 0) brd_fwd<float, 1><<<grid, 256, 0, st>>>((const float*)a, (const float*)bias, totalv, C, thr, scale, seed, offset, (float*)h);
-  else if (dtype == 1 && V == 2) brd_fwd<__hip_bfloat16, 2><<<grid, 256, 0, st>>>((const __hip_bfloat16*)a, (const __hip_bfloat16*)bias, totalv, C, thr, scale, seed, offset, (__hip_bfloat16*)h);
-  else if (dtype == 1) brd_fwd<__hip_bfloat16, 1><<<grid, 256, 0, st>>>((const __hip_bfloat16*)a, (const __hip_bfloat16*)bias, totalv, C, thr, scale, seed, offset, (__hip_bfloat16*)h);
+  if (dtype == 0) brd_fwd<float, 1><<<grid, 256, 0, st>>>((const float*)a, (const float*)bias, totalv, C, thr, scale, seed, offset, (const uint64_t*)rng_base, (float*)h);
+  else if (dtype == 1 && V == 2) brd_fwd<__hip_bfloat16, 2><<<grid, 256, 0, st>>>((const __hip_bfloat16*)a, (const __hip_bfloat16*)bias, totalv, C, thr, scale, seed, offset, (const uint64_t*)rng_base, (__hip_bfloat16*)h);
+  else if (dtype == 1) brd_fwd<__hip_bfloat16, 1><<<grid, 256, 0, st>>>((const __hip_bfloat16*)a, (const __hip_bfloat16*)bias, totalv, C, thr, scale, seed, offset, (const uint64_t*)rng_base, (__hip_bfloat16*)h);
   else return -1008;
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;

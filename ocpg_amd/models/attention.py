@@ -5,7 +5,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import amp_cache
+from . import amp_cache, fallbacks
 from .amp_cache import lookup
 from .ops.functions import attn_smallk_func
 
@@ -46,6 +46,8 @@ class MultiheadAttention(nn.Module):
             o = attn_smallk_func.attention(q, k, v, key_padding_mask, hd ** -0.5, H, self.dropout if self.training else 0.0)
             if o is not None:
                 return self.out_proj(o)
+        fallbacks.note("MultiheadAttention", f"head_dim {hd}, {H} heads, {Lk} keys not served by csrc/attn_smallk.hip"
+                       if not (hd == 32 and Lk <= 32 and H <= 8) else "attn_smallk declined the call", query)
         # split the packed projection ONCE (backward: one cat per parameter, not three zero-fill + copy + add chains)
         if query is key:        # decoder self-attention: q and k from the same input -> one GEMM
             wqk, wv = w.split([2 * C, C])

@@ -10,7 +10,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from ...._lib import check, lib, stream_ptr
-from .fused_ln_func import _rng
+from .fused_ln_func import _unpack
 
 _DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 
@@ -39,21 +39,21 @@ class SmallKeyAttention(Function):
         pad = None if key_pad is None else key_pad.to(torch.uint8).contiguous()
         out = torch.empty((Lq, B, C), dtype=q.dtype, device=q.device)
         lse = torch.empty((Lq, B, H), dtype=torch.float32, device=q.device)
-        seed, offset = (0, 0) if pdrop <= 0 else (rng if rng is not None else _rng())
+        seed, offset, base = (0, 0, None) if pdrop <= 0 else _unpack(rng)
         with torch.cuda.device(q.device):
             rc = lib().ocpg_attn_smallk_fwd(q.data_ptr(), ldq, k.data_ptr(), ldk, v.data_ptr(), ldv, None if pad is None else pad.data_ptr(),
-                                            float(scale), Lq, B, H, C // H, Lk, float(pdrop), seed, offset, out.data_ptr(), C,
+                                            float(scale), Lq, B, H, C // H, Lk, float(pdrop), seed, offset, base, out.data_ptr(), C,
                                             lse.data_ptr(), _DT[q.dtype], stream_ptr())
         check(rc, "ocpg_attn_smallk_fwd")
         ctx.save_for_backward(q, k, v, pad, lse)
-        ctx.meta = (float(scale), H, float(pdrop), seed, offset, ldq, ldk, ldv)
+        ctx.meta = (float(scale), H, float(pdrop), seed, offset, base, ldq, ldk, ldv)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
         q, k, v, pad, lse = ctx.saved_tensors
-        scale, H, pdrop, seed, offset, ldq, ldk, ldv = ctx.meta
+        scale, H, pdrop, seed, offset, base, ldq, ldk, ldv = ctx.meta
         Lq, B, C = q.shape
         Lk = k.shape[0]
         dout = dout.contiguous()
@@ -61,7 +61,7 @@ class SmallKeyAttention(Function):
         dkv = torch.zeros((2, Lk, B, C), dtype=torch.float32, device=q.device)
         with torch.cuda.device(q.device):
             rc = lib().ocpg_attn_smallk_bwd(q.data_ptr(), ldq, k.data_ptr(), ldk, v.data_ptr(), ldv, None if pad is None else pad.data_ptr(),
-                                            dout.data_ptr(), C, lse.data_ptr(), scale, Lq, B, H, C // H, Lk, pdrop, seed, offset,
+                                            dout.data_ptr(), C, lse.data_ptr(), scale, Lq, B, H, C // H, Lk, pdrop, seed, offset, base,
                                             dq.data_ptr(), C, dkv[0].data_ptr(), dkv[1].data_ptr(), _DT[q.dtype], stream_ptr())
         check(rc, "ocpg_attn_smallk_bwd")
         dkv = dkv.to(k.dtype)

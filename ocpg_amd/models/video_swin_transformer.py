@@ -23,7 +23,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import amp_cache
+from . import amp_cache, fallbacks
 
 from ..util.misc import NestedTensor
 from .ops.functions.win_attn_func import window_attention
@@ -168,6 +168,8 @@ class WindowAttention3D(nn.Module):
             out = window_attention(qkv.view(bw, n, 3, h, c // h), bias, region, self.scale, nw)      # csrc/win_attn.hip
             return self.proj_drop(self.proj(out))
         # generic path (CPU unit tests of the host logic, head_dim != 32, attention dropout): torch's fused SDPA
+        fallbacks.note("WindowAttention3D", "generic attention forced (OCPG_GENERIC_WINDOW_ATTENTION)" if _GENERIC_ATTENTION else
+                       f"head_dim {c // h} / attention dropout {self.attn_drop.p} / dense shift mask not served by csrc/win_attn*.hip", x)
         qkv = qkv.view(bw, n, 3, h, c // h).permute(2, 0, 3, 1, 4)
         bias = bias.unsqueeze(0)
         if mask is None and region is not None:          # the additive N x N form of the same shift mask

@@ -13,6 +13,7 @@ source text is stored.  Fixture <-> reference map:
   transformer      DeformableTransformer.forward (deformable_transformer.py:134-217), 2 enc + 2 dec layers
   lfm              LFMResizeAdaptive.forward (modules.py:33-61) without / with incoming gauss_map
   fusion           VisionLanguageFusionModule.forward (segmentation.py:103-113) with key padding
+  *_d32            msda_module / transformer / fusion again with 2 heads of head_dim 32: the shapes the production HIP kernels serve
   dynmask_mso      OCPG.dynamic_mask_with_coords (ocpg.py:475-529) and MSO.forward (decoder.py:31-46)
   matcher_crit     HungarianMatcher.forward (matcher.py:74-171) and SetCriterion.forward (criterion.py:213-254)
   e2e_tiny         OCPG.forward + criterion + backward (ocpg.py:197-447), train mode, with / without padding,
@@ -107,10 +108,10 @@ def gen_msda_cases():
 
 
 # ----------------------------------------------------------------------------------------------
-def gen_msda_module():
+def gen_msda_module(name="msda_module", M=8):
     ref_import.install()
     from models.ops.modules import MSDeformAttn
-    d, L, M, P = 64, 4, 8, 4
+    d, L, P = 64, 4, 4
     shapes_l = [(8, 12), (4, 6), (2, 3), (1, 2)]
     shapes, lsi = level_start(shapes_l)
     S = int(shapes.prod(1).sum())
@@ -133,16 +134,16 @@ def gen_msda_module():
         arrays.update({f"{tag}_out": out, f"{tag}_loc": loc, f"{tag}_attn": attn, f"{tag}_gq": grads[0], f"{tag}_gsrc": grads[1]})
         for (k, _), g in zip(mod.named_parameters(), grads[2:]):
             arrays[f"{tag}_gp_{k}"] = g
-    save("msda_module", {"d": d, "L": L, "M": M, "P": P, "shapes": shapes_l, "N": N, "Lq": Lq, "seed": 2,
+    save(name, {"d": d, "L": L, "M": M, "P": P, "shapes": shapes_l, "N": N, "Lq": Lq, "seed": 2,
                          "pad_frac_h": [1.0, 0.75], "pad_frac_w": [1.0, 0.6], "param_shapes": synth.shapes_of(mod)}, pad=pad, **arrays)
 
 
-def gen_transformer():
+def gen_transformer(name="transformer", nhead=8):
     ref_import.install()
     from models.deformable_transformer import DeformableTransformer
     d, ffn, L = 64, 128, 4
     shapes_l = [(8, 12), (4, 6), (2, 3), (1, 2)]
-    tr = DeformableTransformer(d_model=d, nhead=8, num_encoder_layers=2, num_decoder_layers=2, dim_feedforward=ffn,
+    tr = DeformableTransformer(d_model=d, nhead=nhead, num_encoder_layers=2, num_decoder_layers=2, dim_feedforward=ffn,
                                dropout=0.0, return_intermediate_dec=True, num_feature_levels=L,
                                dec_n_points=4, enc_n_points=4)
     from models.ocpg import MLP, _get_clones
@@ -173,7 +174,7 @@ def gen_transformer():
         gn[k] = float(g.norm()) if g is not None else None
     for i, m in enumerate(masks):
         arrays[f"mask{i}"] = m
-    save("transformer", {"d": d, "ffn": ffn, "L": L, "shapes": shapes_l, "B": B, "T": T, "Q": Q, "seed": 3,
+    save(name, {"d": d, "nhead": nhead, "ffn": ffn, "L": L, "shapes": shapes_l, "B": B, "T": T, "Q": Q, "seed": 3,
                          "enc": 2, "dec": 2, "param_shapes": shp, "grad_norms": gn}, **arrays)
 
 
@@ -200,11 +201,11 @@ def gen_lfm():
     save("lfm", {"c": c, "sigma": 7, "seed": 4, "param_shapes": shp}, **arrays)
 
 
-def gen_fusion():
+def gen_fusion(name="fusion", nhead=8):
     ref_import.install()
     from models.segmentation import VisionLanguageFusionModule
     d = 64
-    mod = VisionLanguageFusionModule(d_model=d, nhead=8)
+    mod = VisionLanguageFusionModule(d_model=d, nhead=nhead)
     shp = synth.shapes_of(mod)
     mod.load_state_dict(synth.synth_state_dict(shp, seed=5))
     t, h, w, b, Lt = 2, 3, 5, 2, 6
@@ -220,7 +221,7 @@ def gen_fusion():
     arrays = dict(out=out, gvis=grads[0], gtext=grads[1], pad=pm)
     for (k, _), g in zip(params.items(), grads[2:]):
         arrays["gp_" + k] = g
-    save("fusion", {"d": d, "seed": 5, "t": t, "h": h, "w": w, "b": b, "Lt": Lt, "param_shapes": shp}, **arrays)
+    save(name, {"d": d, "nhead": nhead, "seed": 5, "t": t, "h": h, "w": w, "b": b, "Lt": Lt, "param_shapes": shp}, **arrays)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -713,6 +714,10 @@ GENS = {"msda_testpy": gen_msda_testpy, "msda_cases": gen_msda_cases, "msda_modu
         "transformer": gen_transformer, "lfm": gen_lfm, "fusion": gen_fusion, "dynmask_mso": gen_dynmask_mso,
         "matcher_crit": gen_matcher_crit, "e2e_tiny": gen_e2e_tiny, "e2e_d32": gen_e2e_d32, "e2e_cfg1": gen_e2e_cfg1,
         "train_step": gen_train_step,
+        # head_dim 32 (d 64 / 2 heads): the module-level reference vectors reach the production kernels (msda_*<8>, attn_smallk)
+        "msda_module_d32": lambda: gen_msda_module("msda_module_d32", M=2),
+        "transformer_d32": lambda: gen_transformer("transformer_d32", nhead=2),
+        "fusion_d32": lambda: gen_fusion("fusion_d32", nhead=2),
         "swin3d": gen_swin3d, "swin_n392": gen_swin_n392, "e2e_swin": gen_e2e_swin, "clip_transforms": gen_clip_transforms}
 
 if __name__ == "__main__":

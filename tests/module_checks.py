@@ -36,7 +36,7 @@ def check_lfm(g, dev, rtol=1e-4, atol=1e-5):
 def check_fusion(g, dev, rtol=1e-4, atol=1e-5):
     from ocpg_amd.models.segmentation import VisionLanguageFusionModule
     m = g.meta
-    mod = VisionLanguageFusionModule(d_model=m["d"], nhead=8)
+    mod = VisionLanguageFusionModule(d_model=m["d"], nhead=m.get("nhead", 8))
     mod.load_state_dict(synth.synth_state_dict(m["param_shapes"], seed=m["seed"]))
     mod.to(dev)
     t, h, w, b, Lt, d = m["t"], m["h"], m["w"], m["b"], m["Lt"], m["d"]
@@ -87,7 +87,7 @@ def check_transformer(g, dev, rtol=2e-4, atol=2e-5):
     from ocpg_amd.models.ocpg import MLP, _get_clones
     m = g.meta
     d, L = m["d"], m["L"]
-    tr = DeformableTransformer(d_model=d, nhead=8, num_encoder_layers=m["enc"], num_decoder_layers=m["dec"], dim_feedforward=m["ffn"],
+    tr = DeformableTransformer(d_model=d, nhead=m.get("nhead", 8), num_encoder_layers=m["enc"], num_decoder_layers=m["dec"], dim_feedforward=m["ffn"],
                                dropout=0.0, return_intermediate_dec=True, num_feature_levels=L, dec_n_points=4, enc_n_points=4)
     tr.decoder.bbox_embed = _get_clones(MLP(d, d, 4, 3), m["dec"])
     tr.load_state_dict(synth.synth_state_dict(m["param_shapes"], seed=m["seed"]))

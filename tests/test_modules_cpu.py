@@ -30,6 +30,14 @@ def test_transformer(golden, msda_double):
     mc.check_transformer(golden("transformer"), CPU)
 
 
+@pytest.mark.parametrize("name,check", [("fusion_d32", "check_fusion"), ("msda_module_d32", "check_msda_module"),
+                                        ("transformer_d32", "check_transformer")])
+def test_head_dim_32_fixtures_host_logic(golden, msda_double, name, check):
+    """The head_dim-32 reference vectors (2 heads x 32) against the host logic on the CPU; the -m gpu twins of these run the
+    production HIP kernels and forbid every library fallback."""
+    getattr(mc, check)(golden(name), CPU)
+
+
 def test_dynmask_mso(golden):
     mc.check_dynmask_mso(golden("dynmask_mso"), CPU)
 
