@@ -27,6 +27,7 @@
 
 #include "../../include/ocpg_hip.h"
 #include "msda_col.h"
+#include "msda_tile.h"
 #include "msda_dev.h"
 
 namespace {
@@ -867,6 +868,11 @@ inline int launch_bwd_value_col(const float* loc, const float* attn, const float
                                 int M, int D, int L, int Lq, int P, float* grad_value, hipStream_t st) {
   const int G = fast_group(D);
   if (!(shapes_host && Lq == S && col_enabled() && (G == 4 || G == 8) && (long long)S * M * D < (1LL << 31))) return 0;
+  // round 3: output-tiled kernels (plain stores for the fine levels, no halo re-flush: csrc/msda_tile.hip).  Measured at config #2,
+  // N = 10 (tools/bench_msda_gv.py, profiles/r03_msda_gv_paths.json): 261-280 us against the column scatter's 213 us on the model's
+  // INITIAL ring offsets, 334-364 against 502 us on perturbed ("trained") offsets -- opt-in (OCPG_MSDA_TILE=1) until it wins both.
+  const char* te = std::getenv("OCPG_MSDA_TILE");
+  if (te && te[0] == '1' && ocpg_tile::bwd_value_tile(loc, attn, grad_out, shapes_host, N, S, M, D, L, P, grad_value, st)) return 1;
   ocpg_col::ColGeom cg;
   const char* tw = std::getenv("OCPG_MSDA_TILEW");      // experiment switch: scatter tile width on the finest level
   if (!ocpg_col::make_col_geom(shapes_host, L, S, M, P, 8, tw ? std::atoi(tw) : 16, cg)) return 0;

@@ -219,8 +219,10 @@ class _env:
                          ids=["cfg2", "cfg5", "cfg1_3lvl", "ragged"])
 def test_self_attention_kernels_vs_c_oracle(dev, shapes_l):
     """Forward + backward on locality-structured inputs, element-wise against the C oracle (one frame keeps the CPU side
-    to seconds), for every path that serves Lq == S: default (row forward, column scatter + row gather backward),
-    the LDS-window forward (OCPG_MSDA_FWD=col) and the round-1 kernels (OCPG_MSDA_COL=0)."""
+    to seconds), for every path that serves Lq == S: default (row forward, column scatter + row gather backward), the
+    output-tiled grad_value kernels (round 3, csrc/msda_tile.hip, OCPG_MSDA_TILE=1), the LDS-window forward (OCPG_MSDA_FWD=col)
+    and the round-1 kernels (OCPG_MSDA_COL=0).  The inputs hold samples within the tile margin, beyond it (far corners: atomics of the
+    coarse kernel) and outside the map."""
     from oracle import msda as om
     from ocpg_amd.models.ops.functions import ms_deform_attn_backward, ms_deform_attn_forward
     value, shapes, ls, loc, attn, go = _local_inputs(dev, 1, shapes_l)
@@ -229,7 +231,7 @@ def test_self_attention_kernels_vs_c_oracle(dev, shapes_l):
     dv, dl, da, dg = (t.to(dev) for t in (value, loc, attn, go))
     ds, dls = shapes.to(dev), ls.to(dev)
     ds._ocpg_host = shapes
-    for env in ({}, {"OCPG_MSDA_FWD": "col"}, {"OCPG_MSDA_COL": "0"}):
+    for env in ({}, {"OCPG_MSDA_TILE": "1"}, {"OCPG_MSDA_FWD": "col"}, {"OCPG_MSDA_COL": "0"}):
         with _env(**env):
             out = ms_deform_attn_forward(dv, ds, dls, dl, da)
             gv, gl, ga = ms_deform_attn_backward(dv, ds, dls, dl, da, dg)
@@ -255,6 +257,9 @@ def test_self_attention_backward_paths_agree_at_bench_size(dev):
         gv0, gl0, ga0 = ms_deform_attn_backward(value, ds, dls, loc, attn, go)
     scale = gv0.abs().max()
     assert (gv - gv0).abs().max() <= 2e-5 * scale
+    with _env(OCPG_MSDA_TILE="1"):                                  # the output-tiled kernels (tile stores + coarse / far atomics)
+        gv1, _, _ = ms_deform_attn_backward(value, ds, dls, loc, attn, go)
+    assert (gv1 - gv0).abs().max() <= 2e-5 * scale
     assert (gl - gl0).abs().max() <= 2e-5 * gl0.abs().max() and torch.allclose(ga, ga0, rtol=1e-3, atol=1e-4)
     lhs = (out.double() * go.double()).sum()
     assert torch.allclose(lhs, (gv.double() * value.double()).sum(), rtol=1e-4)

@@ -1,0 +1,80 @@
+"""grad_value half of the MSDeformAttn backward at the encoder shape: output-tiled kernels (round 3, csrc/msda_tile.hip,
+OCPG_MSDA_TILE=1) against the column scatter (default), HIP events around the C-ABI call only (the zero fill is outside), on
+  ring     the model's initial offsets (ms_deform_attn.py:64-78),
+  ring+n   + gaussian noise (sigma 1.5 px) and 2 % far outliers,
+  trained  + gaussian noise of sigma 3 px and 5 % far outliers (what the roofline row "perturbed offsets" is measured on).
+Prints one JSON line per (mode, path)."""
+import ctypes
+import json
+import math
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ocpg_amd._lib import lib, stream_ptr
+
+dev = torch.device("cuda:0")
+shapes_l = [(48, 80), (24, 40), (12, 20), (6, 10)]
+if os.environ.get("MSDA_SHAPES") == "davis":
+    shapes_l = [(60, 108), (30, 54), (15, 27), (8, 14)]
+shapes = torch.tensor(shapes_l, dtype=torch.long)
+S = int(shapes.prod(1).sum())
+N, M, D, L, P = int(os.environ.get("MSDA_FRAMES", "10")), 8, 32, 4, 4
+
+
+def ring_loc(noise, outliers, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    refs = []
+    for (h, w) in shapes_l:
+        ys, xs = torch.meshgrid(torch.linspace(0.5, h - 0.5, h) / h, torch.linspace(0.5, w - 0.5, w) / w, indexing="ij")
+        refs.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], -1))
+    ref = torch.cat(refs, 0)[None, :, None, None, None, :]
+    th = torch.arange(M) * (2 * math.pi / M)
+    grid = torch.stack([th.cos(), th.sin()], -1)
+    grid = grid / grid.abs().max(-1, keepdim=True)[0]
+    off = (grid.view(1, 1, M, 1, 1, 2) * torch.arange(1, P + 1).view(1, 1, 1, 1, P, 1)).expand(N, S, M, L, P, 2)
+    if noise:
+        off = off + noise * torch.randn(N, S, M, L, P, 2, generator=g)
+    norm = torch.tensor([[w, h] for h, w in shapes_l], dtype=torch.float32).view(1, 1, 1, L, 1, 2)
+    loc = (ref + off / norm).contiguous()
+    if outliers:
+        far = torch.rand(N, S, M, L, P, 1, generator=g) < outliers
+        loc = torch.where(far, torch.rand(N, S, M, L, P, 2, generator=g) * 1.2 - 0.1, loc)
+    return loc.contiguous()
+
+
+def run(loc, attn, go, gv, iters):
+    rc = lib().ocpg_msda_bwd_value_f32(loc.data_ptr(), attn.data_ptr(), go.data_ptr(), N, S, M, D, L, S, P, gv.data_ptr(),
+                                       ctypes.c_void_p(shapes.data_ptr()), stream_ptr())
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    e = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in e:
+        gv.zero_()
+        a.record()
+        lib().ocpg_msda_bwd_value_f32(loc.data_ptr(), attn.data_ptr(), go.data_ptr(), N, S, M, D, L, S, P, gv.data_ptr(),
+                                      ctypes.c_void_p(shapes.data_ptr()), stream_ptr())
+        b.record()
+    torch.cuda.synchronize()
+    return sorted(a.elapsed_time(b) * 1e3 for a, b in e)[iters // 2]
+
+
+algo = 4 * N * (S * M * D + S * M * D + 3 * S * M * L * P)        # read loc, attn, grad_out; write grad_value
+g = torch.Generator().manual_seed(1)
+attn = torch.softmax(torch.randn(N, S, M, L * P, generator=g), -1).view(N, S, M, L, P).to(dev)
+go = torch.randn(N, S, M * D, generator=g).to(dev)
+for mode, (noise, outl) in (("ring", (0.0, 0.0)), ("ring+n", (1.5, 0.02)), ("trained", (3.0, 0.05))):
+    loc = ring_loc(noise, outl).to(dev)
+    res = {}
+    for tile in ("1", "0"):
+        os.environ["OCPG_MSDA_TILE"] = tile
+        gv = torch.zeros(N, S, M, D, device=dev)
+        us = run(loc, attn, go, gv, int(os.environ.get("ITERS", "30")))
+        res[tile] = gv
+        print(json.dumps({"mode": mode, "path": "tile" if tile == "1" else "column", "n_frames": N, "us": round(us, 1),
+                          "algorithmic_bytes": algo, "GBs": round(algo / us / 1e3, 1), "frac_of_8TBs": round(algo / us / 1e3 / 8000, 4)}), flush=True)
+    d = (res["1"] - res["0"]).abs().max().item() / res["0"].abs().max().item()
+    print(json.dumps({"mode": mode, "tile_vs_column_max_rel": d}), flush=True)
+    assert d < 3e-5, d
+os.environ.pop("OCPG_MSDA_TILE", None)
