@@ -104,6 +104,8 @@ def forward_backward(model, criterion, samples, text, targets, amp_dtype, num_bo
         loss_dict, *_ = criterion(out, targets)
         loss = criterion.weighted_sum(loss_dict)        # = sum(loss_dict[k] * weight_dict[k]) (engine.py:56), one reduction
     (scaler.scale(loss) if scaler is not None else loss).backward()
+    from ocpg_amd.models import amp_cache
+    amp_cache.join_wgrad()      # (a no-op after FusedCast.backward; a capture must not end with an un-joined side stream)
     if keep is not None:        # static graph outputs (the usual whole-network-capture rule: keep them referenced)
         keep.update(out=out, loss_dict=loss_dict, loss=loss)
     return loss.detach()
@@ -274,9 +276,11 @@ class GraphStep:
         return self.loss
 
 
-def time_msda_kernels(n_frames, device, iters=20):
+def time_msda_kernels(n_frames, device, iters=20, noise=0.0, outliers=0.0):
     """Live HIP-event timing of the MSDeformAttn kernels at the encoder / decoder shapes of this run, on the launch
-    stream (used when the step itself is a graph replay, where per-kernel events cannot be interleaved)."""
+    stream (used when the step itself is a graph replay, where per-kernel events cannot be interleaved).  noise / outliers:
+    gaussian noise (pixels) on the model's initial ring offsets and a share of samples anywhere in the map -- what trained
+    offsets look like to the kernels (only the encoder shape is timed then)."""
     from ocpg_amd.models.ops.functions import ms_deform_attn_func as f
     shapes_l = [((HEIGHT + 31) // 32 * 32 // 8 >> i, (WIDTH + 31) // 32 * 32 // 8 >> i) for i in range(4)]
     shapes = torch.tensor(shapes_l, dtype=torch.long)
@@ -286,7 +290,7 @@ def time_msda_kernels(n_frames, device, iters=20):
     sh._ocpg_host = shapes
     g = torch.Generator().manual_seed(0)
     out = {}
-    for tag, Lq in (("enc", S), ("dec", 5)):
+    for tag, Lq in ((("enc", S),) if noise or outliers else (("enc", S), ("dec", 5))):
         value = torch.randn(n_frames, S, 8, 32, generator=g).to(device)
         if Lq == S:      # the model's own pattern at init: reference point = the pixel itself, ring offsets of 1..4 px
             import math
@@ -299,7 +303,13 @@ def time_msda_kernels(n_frames, device, iters=20):
             ring = torch.stack([th.cos(), th.sin()], -1)
             ring = (ring / ring.abs().max(-1, keepdim=True)[0]).view(1, 1, 8, 1, 1, 2) * torch.arange(1, 5).view(1, 1, 1, 1, 4, 1)
             norm = torch.tensor([[w, h] for h, w in shapes_l], dtype=torch.float32).view(1, 1, 1, 4, 1, 2)
-            loc = (ref + ring / norm).expand(n_frames, S, 8, 4, 4, 2).contiguous().to(device)
+            loc = (ref + ring / norm).expand(n_frames, S, 8, 4, 4, 2)
+            if noise:
+                loc = loc + noise * torch.randn(n_frames, S, 8, 4, 4, 2, generator=g) / norm
+            if outliers:
+                far = torch.rand(n_frames, S, 8, 4, 4, 1, generator=g) < outliers
+                loc = torch.where(far, torch.rand(n_frames, S, 8, 4, 4, 2, generator=g) * 1.2 - 0.1, loc)
+            loc = loc.contiguous().to(device)
         else:
             loc = torch.rand(n_frames, Lq, 8, 4, 4, 2, generator=g).to(device)
         attn = torch.softmax(torch.randn(n_frames, Lq, 8, 16, generator=g), -1).view(n_frames, Lq, 8, 4, 4).to(device)
@@ -315,7 +325,8 @@ def time_msda_kernels(n_frames, device, iters=20):
     return out
 
 
-VALU_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32 vector peak
+VALU_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32 vector peak (= the fp32-input MFMA peak)
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak (the 5 PF headline figure includes 2:1 sparsity)
 
 
 def _esz(code):
@@ -332,13 +343,27 @@ LIB_WORK = {
     "ocpg_bias_relu_dropout_bwd": ("hbm", lambda a: a[2] * a[3] * _esz(a[5]) * 3),
     "ocpg_dynmask_fwd_f32": ("valu", lambda a: a[3] * a[4] * a[6] * a[7] * (2 * 16 * (a[5] + 2) + 2 * 16 * 16)),
     "ocpg_dynmask_bwd_f32": ("valu", lambda a: 2 * a[3] * a[4] * a[6] * a[7] * (2 * 16 * (a[5] + 2) + 2 * 16 * 16)),
+    # matrix-core kernels: FLOPs = 2 * M * N * K (* batch); bf16 / fp16 storage -> the 2.5 PF peak, fp32 GEMMs -> the 157 TF fp32 peak
+    "ocpg_gemm": ("mfma", lambda a: 2.0 * a[8] * a[9] * a[10] * max(a[14], 1), lambda a: a[4] != 0),
+    "ocpg_gemm_bn_act": ("mfma", lambda a: 2.0 * a[8] * a[9] * a[10], lambda a: a[7] != 0),
+    "ocpg_conv3x3_mfma_fwd": ("mfma", lambda a: 2.0 * a[5] * ((a[6] - 1) // a[10] + 1) * ((a[7] - 1) // a[10] + 1) * 9 * a[8] * a[9], lambda a: True),
+    "ocpg_conv3x3_mfma_dgrad": ("mfma", lambda a: 2.0 * a[2] * ((a[3] - 1) // a[7] + 1) * ((a[4] - 1) // a[7] + 1) * 9 * a[5] * a[6], lambda a: True),
+    "ocpg_small_linear_fwd": ("mfma", lambda a: 2.0 * a[4] * a[5] * a[6], lambda a: True),
+    "ocpg_small_linear_bwd": ("mfma", lambda a: 4.0 * a[6] * a[7] * a[8], lambda a: True),
+    "ocpg_win_attn_fwd": ("mfma", lambda a: 4.0 * a[4] * a[7] * a[6] * a[6] * a[8], lambda a: a[11] != 0),
+    "ocpg_win_attn_bwd_mfma": ("mfma", lambda a: 10.0 * a[5] * a[8] * a[7] * a[7] * a[9], lambda a: True),
 }
 
 
 def lib_work(name, args):
+    """Work of one call (algorithmic bytes or FLOPs); for matrix-core symbols a pair (FLOPs, low-precision operands?)."""
     f = LIB_WORK.get(name)
     try:
-        return float(f[1](args)) if f else None
+        if not f:
+            return None
+        if f[0] == "mfma":
+            return float(f[1](args)), bool(f[2](args))
+        return float(f[1](args))
     except (TypeError, IndexError):
         return None
 
@@ -372,6 +397,11 @@ def kernel_table(msda_kt, lib_kt, n_frames, steps, lib_steps):
             q = d["work"] / d["n"]
             if LIB_WORK[k][0] == "hbm":
                 row.update(bound="hbm", algorithmic_bytes=q, achieved_GBs=q / us / 1e3, frac=q / us / 1e3 / HBM_PEAK_GBS)
+            elif LIB_WORK[k][0] == "mfma":
+                # calls of one symbol mix bf16 and fp32 operands (ocpg_gemm): the peak is weighted by each call's FLOPs
+                peak = (d.get("work_lowp", 0.0) * MFMA_BF16_PEAK_TFLOPS + (d["work"] - d.get("work_lowp", 0.0)) * VALU_PEAK_TFLOPS) / d["work"]
+                row.update(bound="mfma", flops=q, achieved_TFLOPs=q / us / 1e6, peak_TFLOPs=peak, frac=q / us / 1e6 / peak,
+                           lowp_flop_share=d.get("work_lowp", 0.0) / d["work"])
             else:
                 row.update(bound="valu_fp32", flops=q, achieved_TFLOPs=q / us / 1e6, frac=q / us / 1e6 / VALU_PEAK_TFLOPS)
         rows.append(row)
@@ -418,6 +448,7 @@ def main():
                     help="features: random [B,9,768] text features (configs #1-#4); roberta: captions through RoBERTa-base (config #5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-b1", action="store_true", help="skip the extra B = 1 leg (1 clip per GPU and step) after the timed run")
     ap.add_argument("--eager", action="store_true",
                     help="launch every kernel eagerly (DistributedDataParallel for N > 1).  Default: forward + criterion + backward "
                          "replayed as ONE HIP graph (the eager step is host-bound: ~2 600 launches, 45 ms vs 40 ms); the graph is "
@@ -629,8 +660,36 @@ def main():
                                 "launch_us": dom["us"], "algorithmic_bytes": dom["algorithmic_bytes"],
                                 "launches_timed": int(round(dom["launches_per_step"] * kt_steps)),
                                 "timed_in": "the timed steps" if mode == "eager" else f"{kt_steps} extra eager steps after the timed (graph) steps"}
+            if world == 1 and not a.no_kernel_timing and (HEIGHT, WIDTH) == (384, 640):
+                # the same kernel on perturbed ("trained-like") offsets: +3 px gaussian noise, 5 % of the samples anywhere in the map
+                pk = time_msda_kernels(a.clips_per_gpu * T_FRAMES, device, noise=3.0, outliers=0.05).get("bwd_enc_value")
+                if pk and pk["n"]:
+                    us = pk["ms"] / pk["n"] * 1e3
+                    line["roofline_perturbed_offsets"] = {"kernel": line["roofline"]["kernel"], "offsets": "ring + N(0, 3 px) + 5 % uniform",
+                                                          "launch_us": us, "achieved": dom["algorithmic_bytes"] / us / 1e3, "unit": "GB/s",
+                                                          "frac": dom["algorithmic_bytes"] / us / 1e3 / HBM_PEAK_GBS}
         if rows:
-            line["kernels"] = rows[:12]
+            line["kernels"] = rows[:16]
+        from ocpg_amd.models import fallbacks
+        line["library_fallbacks"] = fallbacks.snapshot()         # attention calls that left the HIP kernels for torch SDPA: {} at config #2
+        if world == 1 and mode != "eager" and not a.no_b1 and a.clips_per_gpu != 1:
+            # BASELINE config #2 as SURVEY section 8 words it (B = 1 clip per GPU and step) from the same process; the headline `value`
+            # is the throughput configuration (2 clips per GPU and step = config #3's per-GPU batch)
+            try:
+                mk1, text1, targets1 = synthetic_batch(1, device, seed=42 + rank, roberta=a.text == "roberta")
+                step1 = GraphStep(model, criterion, optimizer, mk1, text1, targets1, args, amp_dtype, world)
+                for _ in range(3):
+                    step1()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(a.steps):
+                    l1 = step1()
+                torch.cuda.synchronize()
+                d1 = time.perf_counter() - t1
+                line["b1"] = {"clips_per_gpu": 1, "value": a.steps / d1, "unit": "clips/s", "ms_per_step": d1 / a.steps * 1e3, "steps": a.steps,
+                              "final_loss": float(l1.detach())}
+            except Exception as e:      # never lose the headline line to the extra leg
+                line["b1"] = {"error": f"{type(e).__name__}: {str(e)[:160]}"}
         if world == 1 and not a.no_cpu_baseline and a.backbone.startswith("resnet"):
             line["cpu_baseline"] = cpu_baseline({k: tuple(v.shape) for k, v in model.state_dict().items() if v.dtype.is_floating_point})
         print(json.dumps(line), flush=True)

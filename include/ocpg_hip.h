@@ -8,14 +8,20 @@
  *
  * Conventions (all entry points):
  *   - plain device pointers + sizes, no torch types; every tensor contiguous, row-major, same device;
- *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); launches are asynchronous,
- *     nothing in the library synchronises or allocates;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); launches are asynchronous.  The KERNEL entry points
+ *     neither synchronise nor allocate.  ONE exception, the GEMM family (ocpg_gemm, ocpg_gemm_bn_act: csrc/gemm.hip): it keeps a
+ *     per-device PLAN CACHE (mutex-protected) and, at the FIRST use of a (device, stream) pair / of a plan, hipMallocs a hipBLASLt
+ *     workspace and -- with OCPG_GEMM_TUNE=1, the default -- scratch outputs to time the heuristic's candidates, synchronising on
+ *     its own events while it does.  Consequences for callers: run one un-captured call per shape and stream before capturing a
+ *     HIP graph (bench.py's warm-up steps on the capture stream); OCPG_GEMM_TUNE=0 pins the heuristic's first choice
+ *     (run-to-run and rank-to-rank reproducible kernel selection);
  *   - return 0 on success, a negative hipError_t on a launch/runtime error, -1000-k for the k-th
  *     argument being invalid (null pointer / non-positive size);
  *   - outputs are caller-allocated.  Forward outputs are fully overwritten.  In the backward,
  *     grad_value is ACCUMULATED into (scatter-add): the caller zeroes it first, exactly as
  *     ms_deform_attn_cuda.cu:121 does with at::zeros_like; grad_loc / grad_attn are fully overwritten;
- *   - re-entrant and thread-safe (no global state).
+ *   - re-entrant and thread-safe; no global state except the GEMM plan cache above (and, in diagnostic builds only, the
+ *     EXP_STAMPS counters).
  *
  * Tensor contract of MSDeformAttn (ms_deform_attn_cuda.cu:28-48):
  *   value        [N, S, M, D]          S = sum_l H_l*W_l

@@ -106,6 +106,9 @@ def collect_kernel_timing(work=None):
         d["ms"] += e0.elapsed_time(e1)
         d["n"] += 1
         w = work(name, args) if work is not None else None
+        if isinstance(w, tuple):            # (FLOPs, low-precision operands): matrix-core symbols
+            d["work_lowp"] = d.get("work_lowp", 0.0) + (w[0] if w[1] else 0.0)
+            w = w[0]
         if w is not None:
             d["work"] += w
             d["modelled"] += 1

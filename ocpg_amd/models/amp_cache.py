@@ -29,6 +29,68 @@ SPLIT_K = os.environ.get("OCPG_SPLIT_K", "1") != "0"      # A/B switch: weight g
 
 
 MULTI_CAST = True   # A/B switch: one HIP launch for all parameter casts / gradient casts (csrc/multi_cast.hip)
+
+# ---- weight gradients on a side stream --------------------------------------------------------------------------------------
+# In the backward of a layer only the INPUT gradient is on the critical path; the weight gradient is first read by
+# FusedCast.backward, the very last node of the backward pass.  The fused conv nodes of the ResNet body therefore compute it on
+# a second stream: in eager mode the two streams overlap, and a captured step gets PARALLEL BRANCHES in its HIP graph instead
+# of one chain (most of these kernels do not fill 256 CUs, and a chain pays every launch gap).  Only for weights that are
+# FusedCast copies used ONCE per forward (the engine would otherwise sum two gradients on the main stream before the join).
+WGRAD_STREAM = os.environ.get("OCPG_WGRAD_STREAM", "0") != "0"     # measured (round 3, graph mode): 42.1 ms with, 40.3 ms without -- the HIP graph executor does not overlap the branches; kept as an A/B switch
+_side_streams = {}
+_side_pending = {}
+
+
+class side_wgrad:
+    """`with side_wgrad(flag, *inputs) as sw: ...` runs the body on the device's weight-gradient stream when `flag` (the weight is
+    a FusedCast copy: is_cast_copy, decided in the node's forward); the inputs are marked as used there (the allocator must not hand their memory out again before that stream is done);
+    outputs allocated inside belong to the side stream and are marked as used on the main stream by `publish`."""
+
+    def __init__(self, on, *inputs):
+        self.on = bool(on and WGRAD_STREAM and inputs[0].is_cuda)
+        self.inputs = inputs
+
+    def __enter__(self):
+        if not self.on:
+            return self
+        self.main = torch.cuda.current_stream()
+        dev = self.main.device
+        side = _side_streams.get(dev)
+        if side is None:
+            side = _side_streams[dev] = torch.cuda.Stream(device=dev)
+        self.side = side
+        side.wait_stream(self.main)
+        for t in self.inputs:
+            t.record_stream(side)
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        _side_pending[dev] = True
+        return self
+
+    def publish(self, t):
+        if self.on:
+            t.record_stream(self.main)
+        return t
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def is_cast_copy(w):
+    """True for the low-precision working copy FusedCast made of a parameter (its gradient is first read by FusedCast.backward)."""
+    return w.grad_fn is not None and w.grad_fn.name() == "FusedCastBackward"
+
+
+def join_wgrad():
+    """The main stream waits for every weight gradient computed on the side stream (FusedCast.backward; end of a backward pass)."""
+    if not _side_pending:
+        return
+    cur = torch.cuda.current_stream()
+    if _side_pending.pop(cur.device, False):
+        cur.wait_stream(_side_streams[cur.device])
+
 _DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 _CHUNK = 2048
 
@@ -155,6 +217,7 @@ class FusedCast(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
+        join_wgrad()            # weight gradients computed on the side stream are first read here
         idx = [i for i, g in enumerate(grads) if g is not None and ctx.needs_input_grad[i + 2]]
         res = [None] * len(grads)
         if idx:

@@ -51,7 +51,9 @@ class Conv1x1BNAct(Function):
             if rc:
                 check(rc, "ocpg_bn_act_fwd")
         ctx.save_for_backward(x, w, y, scale)
+        from ...amp_cache import is_cast_copy
         ctx.meta = (bool(relu), skip is not None, splits)
+        ctx.w_cast = is_cast_copy(w)
         return y
 
     @staticmethod
@@ -81,18 +83,21 @@ class Conv1x1BNAct(Function):
             if rc:
                 check(rc, "ocpg_gemm")
         if need_w:      # gw[co, c] = gz[m, co]^T x[m, c], rows split into `splits` chunks (one strided-batched GEMM + a sum)
-            if splits > 1 and m % splits == 0:
-                r = m // splits
-                part = torch.empty((splits, co, c), dtype=x.dtype, device=x.device)
-                rc = L.ocpg_gemm(gz.data_ptr(), x.data_ptr(), part.data_ptr(), None, dt, dt, 1, 0, co, c, r, co, c, c, splits, r * co, r * c,
-                                 co * c, 1.0, 0.0, st)
-                gw = part.sum(0)
-            else:
-                gw = torch.empty((co, c), dtype=x.dtype, device=x.device)
-                rc = L.ocpg_gemm(gz.data_ptr(), x.data_ptr(), gw.data_ptr(), None, dt, dt, 1, 0, co, c, m, co, c, c, 1, 0, 0, 0, 1.0, 0.0, st)
-            if rc:
-                check(rc, "ocpg_gemm")
-            gw = gw.view(w.shape)
+            from ...amp_cache import side_wgrad
+            with side_wgrad(ctx.w_cast, gz, x) as sw:          # off the critical path: the weight-gradient stream (amp_cache.side_wgrad)
+                st = torch.cuda.current_stream().cuda_stream
+                if splits > 1 and m % splits == 0:
+                    r = m // splits
+                    part = torch.empty((splits, co, c), dtype=x.dtype, device=x.device)
+                    rc = L.ocpg_gemm(gz.data_ptr(), x.data_ptr(), part.data_ptr(), None, dt, dt, 1, 0, co, c, r, co, c, c, splits, r * co, r * c,
+                                     co * c, 1.0, 0.0, st)
+                    gw = part.sum(0)
+                else:
+                    gw = torch.empty((co, c), dtype=x.dtype, device=x.device)
+                    rc = L.ocpg_gemm(gz.data_ptr(), x.data_ptr(), gw.data_ptr(), None, dt, dt, 1, 0, co, c, m, co, c, c, 1, 0, 0, 0, 1.0, 0.0, st)
+                if rc:
+                    check(rc, "ocpg_gemm")
+                gw = sw.publish(gw).view(w.shape)
         return gx, gw, None, None, gskip, None, None
 
 
@@ -212,7 +217,9 @@ class Conv3x3MfmaBNAct(Function):
         check(lib().ocpg_conv3x3_mfma_fwd(x.data_ptr(), w2.data_ptr(), scale.data_ptr(), shift.data_ptr(), int(relu), n, h, wd, c, co, stride,
                                           y.data_ptr(), st), "ocpg_conv3x3_mfma_fwd")
         ctx.save_for_backward(x, w2, y, scale)
+        from ...amp_cache import is_cast_copy
         ctx.meta = (bool(relu), splits, stride)
+        ctx.w_cast = is_cast_copy(w)
         return y
 
     @staticmethod
@@ -235,19 +242,22 @@ class Conv3x3MfmaBNAct(Function):
             gx = torch.empty((n, c, h, wd), dtype=y.dtype, device=y.device, memory_format=_CL)
             check(L.ocpg_conv3x3_mfma_dgrad(gz.data_ptr(), wt.data_ptr(), n, h, wd, c, co, stride, gx.data_ptr(), st), "ocpg_conv3x3_mfma_dgrad")
         if ctx.needs_input_grad[1]:
-            cols = torch.empty((m, k), dtype=y.dtype, device=y.device)
-            check(L.ocpg_im2col3x3_nhwc(x.data_ptr(), n, h, wd, c, stride, 1, cols.data_ptr(), 1, st), "ocpg_im2col3x3_nhwc")
-            if splits > 1 and m % splits == 0:
-                r = m // splits
-                part = torch.empty((splits, co, k), dtype=y.dtype, device=y.device)
-                check(L.ocpg_gemm(gz.data_ptr(), cols.data_ptr(), part.data_ptr(), None, 1, 1, 1, 0, co, k, r, co, k, k, splits, r * co, r * k,
-                                  co * k, 1.0, 0.0, st), "ocpg_gemm")
-                g2 = part.sum(0)
-            else:
-                g2 = torch.empty((co, k), dtype=y.dtype, device=y.device)
-                check(L.ocpg_gemm(gz.data_ptr(), cols.data_ptr(), g2.data_ptr(), None, 1, 1, 1, 0, co, k, m, co, k, k, 1, 0, 0, 0, 1.0, 0.0, st),
-                      "ocpg_gemm")
-            gw = g2.view(co, 3, 3, c).permute(0, 3, 1, 2)          # channels-last strides of [co, c, 3, 3]
+            from ...amp_cache import side_wgrad
+            with side_wgrad(ctx.w_cast, gz, x) as sw:          # off the critical path: the weight-gradient stream (amp_cache.side_wgrad)
+                st = torch.cuda.current_stream().cuda_stream
+                cols = torch.empty((m, k), dtype=y.dtype, device=y.device)
+                check(L.ocpg_im2col3x3_nhwc(x.data_ptr(), n, h, wd, c, stride, 1, cols.data_ptr(), 1, st), "ocpg_im2col3x3_nhwc")
+                if splits > 1 and m % splits == 0:
+                    r = m // splits
+                    part = torch.empty((splits, co, k), dtype=y.dtype, device=y.device)
+                    check(L.ocpg_gemm(gz.data_ptr(), cols.data_ptr(), part.data_ptr(), None, 1, 1, 1, 0, co, k, r, co, k, k, splits, r * co, r * k,
+                                      co * k, 1.0, 0.0, st), "ocpg_gemm")
+                    g2 = part.sum(0)
+                else:
+                    g2 = torch.empty((co, k), dtype=y.dtype, device=y.device)
+                    check(L.ocpg_gemm(gz.data_ptr(), cols.data_ptr(), g2.data_ptr(), None, 1, 1, 1, 0, co, k, m, co, k, k, 1, 0, 0, 0, 1.0, 0.0, st),
+                          "ocpg_gemm")
+                gw = sw.publish(g2).view(co, 3, 3, c).permute(0, 3, 1, 2)          # channels-last strides of [co, c, 3, 3]
         return gx, gw, None, None, None, None, None
 
 
