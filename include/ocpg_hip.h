@@ -252,6 +252,12 @@ long long ocpg_bias_relu_dropout_bwd_slots(long long R, int C, int dtype);
  * dtype codes: 0 fp32, 1 bf16, 2 fp16; supported pairs: fp32 <-> bf16, fp32 <-> fp16. */
 int ocpg_multi_cast(const long long* srcs, const long long* dsts, const long long* numels, const long long* chunk_prefix, int n,
                     long long total_chunks, int src_dtype, int dst_dtype, void* stream);
+/* The same with a reduction on the way: tensor t = sum of splits[t] slices of numels[t] elements, strides[t] elements apart (the
+ * row-split weight-gradient partial products of the fused conv nodes: replaces one at::sum launch per layer, ~90 per step in the
+ * ResNet body of models/backbone.py, plus the cast).  src_dtype 0 fp32 / 1 bf16 / 2 fp16 -> fp32; fp32 accumulation. */
+int ocpg_multi_cast_sum(const long long* srcs, const long long* dsts, const long long* numels, const long long* chunk_prefix,
+                        const long long* splits, const long long* strides, int n, long long total_chunks, int src_dtype, int dst_dtype,
+                        void* stream);
 
 /* Classification (sigmoid focal, alpha < 0 disables the alpha weighting) + L1 + GIoU losses of the matched queries, all layers
  * per launch -- replaces SetCriterion.loss_labels / loss_boxes (models/criterion.py:46-107; sigmoid_focal_loss

@@ -64,6 +64,7 @@ SIGNATURES = {
     "ocpg_bias_relu_dropout_bwd": [_vp, _vp, ctypes.c_longlong, _int, ctypes.c_float, _int, _vp, _vp, _vp],
     "ocpg_bias_relu_dropout_bwd_slots": [ctypes.c_longlong, _int, _int],
     "ocpg_multi_cast": [_vp] * 4 + [_int, ctypes.c_longlong, _int, _int, _vp],
+    "ocpg_multi_cast_sum": [_vp] * 6 + [_int, ctypes.c_longlong, _int, _int, _vp],
     "ocpg_det_loss_fwd_f32": [_vp] * 7 + [ctypes.c_float] + [_int] * 5 + [_vp] * 3,
     "ocpg_det_loss_bwd_f32": [_vp] * 8 + [ctypes.c_float] + [_int] * 5 + [_vp] * 3,
     "ocpg_spectral_gate_fwd": [_vp] * 3 + [_int] * 3 + [_vp, _vp],

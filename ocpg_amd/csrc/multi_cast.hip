@@ -26,6 +26,51 @@ template <> __device__ __forceinline__ float from_f<float>(float v) { return v; 
 template <> __device__ __forceinline__ __hip_bfloat16 from_f<__hip_bfloat16>(float v) { return __float2bfloat16(v); }
 template <> __device__ __forceinline__ __half from_f<__half>(float v) { return __float2half_rn(v); }
 
+// The same with a reduction on the way: tensor t is the SUM of splits[t] slices of numels[t] elements, strides[t] elements apart
+// (the row-split weight-gradient GEMMs of amp_cache.weight_grad leave [splits, Cout, Cin] partial products: one `sum` launch per
+// layer -- ~90 per step in the ResNet body -- and then the cast back to fp32; here both ride in the one launch that casts every
+// gradient).  fp32 accumulation, one rounding.
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void multi_cast_sum(const long long* __restrict__ srcs, const long long* __restrict__ dsts,
+                                                      const long long* __restrict__ numels, const long long* __restrict__ chunk_prefix,
+                                                      const long long* __restrict__ splits, const long long* __restrict__ strides, int n) {
+  const long long blk = blockIdx.x;
+  int lo = 0, hi = n;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (chunk_prefix[mid] <= blk) lo = mid; else hi = mid;
+  }
+  const S* s = reinterpret_cast<const S*>(srcs[lo]);
+  D* d = reinterpret_cast<D*>(dsts[lo]);
+  const long long count = numels[lo], ns = splits[lo], stride = strides[lo];
+  const long long base = (blk - chunk_prefix[lo]) * CHUNK + (long long)threadIdx.x * 8;
+  if (base >= count) return;
+  const bool wide = base + 8 <= count && ((reinterpret_cast<uintptr_t>(s + base) | reinterpret_cast<uintptr_t>(d + base)) & 15) == 0 &&
+                    (ns == 1 || (stride * (long long)sizeof(S)) % 16 == 0);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (wide) {
+    for (long long k = 0; k < ns; ++k) {
+      S in[8];
+      const S* sk = s + k * stride + base;
+      if constexpr (sizeof(S) == 4) { *reinterpret_cast<uint4*>(in) = *reinterpret_cast<const uint4*>(sk); *reinterpret_cast<uint4*>(in + 4) = *reinterpret_cast<const uint4*>(sk + 4); }
+      else *reinterpret_cast<uint4*>(in) = *reinterpret_cast<const uint4*>(sk);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += to_f<S>(in[i]);
+    }
+    D out[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = from_f<D>(acc[i]);
+    if constexpr (sizeof(D) == 4) { *reinterpret_cast<uint4*>(d + base) = *reinterpret_cast<uint4*>(out); *reinterpret_cast<uint4*>(d + base + 4) = *reinterpret_cast<uint4*>(out + 4); }
+    else *reinterpret_cast<uint4*>(d + base) = *reinterpret_cast<uint4*>(out);
+  } else {
+    for (long long i = base; i < base + 8 && i < count; ++i) {
+      float a = 0.f;
+      for (long long k = 0; k < ns; ++k) a += to_f<S>(s[k * stride + i]);
+      d[i] = from_f<D>(a);
+    }
+  }
+}
+
 template <typename S, typename D>
 __global__ __launch_bounds__(256) void multi_cast(const long long* __restrict__ srcs, const long long* __restrict__ dsts,
                                                   const long long* __restrict__ numels, const long long* __restrict__ chunk_prefix, int n) {
@@ -69,6 +114,25 @@ extern "C" int ocpg_multi_cast(const long long* srcs, const long long* dsts, con
   else if (src_dtype == 1 && dst_dtype == 0) MC(__hip_bfloat16, float);
   else if (src_dtype == 2 && dst_dtype == 0) MC(__half, float);
   else return -1010;
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+extern "C" int ocpg_multi_cast_sum(const long long* srcs, const long long* dsts, const long long* numels, const long long* chunk_prefix,
+                                   const long long* splits, const long long* strides, int n, long long total_chunks, int src_dtype,
+                                   int dst_dtype, void* stream) {
+  if (n < 0 || total_chunks < 0) return -1007;
+  if (n == 0 || total_chunks == 0) return 0;
+  if (!srcs || !dsts || !numels || !chunk_prefix) return -1001;
+  if (!splits || !strides) return -1005;
+  if (total_chunks > 2147483647LL) return -1008;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned g = (unsigned)total_chunks;
+#define MCS(S_, D_) multi_cast_sum<S_, D_><<<g, 256, 0, st>>>(srcs, dsts, numels, chunk_prefix, splits, strides, n)
+  if (src_dtype == 1 && dst_dtype == 0) MCS(__hip_bfloat16, float);
+  else if (src_dtype == 2 && dst_dtype == 0) MCS(__half, float);
+  else if (src_dtype == 0 && dst_dtype == 0) MCS(float, float);
+  else return -1011;
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }

@@ -78,6 +78,20 @@ class side_wgrad:
         return False
 
 
+# ---- row-split weight-gradient partials summed inside the fused gradient cast ------------------------------------------------------
+DEFER_SUM = os.environ.get("OCPG_DEFER_WGRAD_SUM", "1") != "0"     # A/B switch
+_PARTIALS = {}          # data_ptr of slice 0 -> (splits, stride in elements, numel of a slice)
+
+
+def defer_sum(part):
+    """part [S, ...] partial products of ONE weight gradient -> slice 0, with the promise that FusedCast.backward adds the other S-1
+    slices while it casts (csrc/multi_cast.hip: multi_cast_sum).  Only for the working copy of a parameter that is used ONCE per
+    forward: the autograd engine must hand this very tensor to FusedCast.backward (it would sum two uses into a new tensor; an
+    entry that nobody consumed raises there)."""
+    _PARTIALS[part.data_ptr()] = (part.shape[0], part.stride(0), part[0].numel())
+    return part[0]
+
+
 def is_cast_copy(w):
     """True for the low-precision working copy FusedCast made of a parameter (its gradient is first read by FusedCast.backward)."""
     return w.grad_fn is not None and w.grad_fn.name() == "FusedCastBackward"
@@ -151,8 +165,14 @@ class _CastPlan:
         prefix = [0]
         for i in idx:
             prefix.append(prefix[-1] + (self.numels[i] + _CHUNK - 1) // _CHUNK)
+        parts = [_PARTIALS.pop(grads[i].data_ptr(), None) if _PARTIALS else None for i in idx]
+        for i, pr in zip(idx, parts):
+            if pr is not None and pr[2] != self.numels[i]:
+                raise RuntimeError("deferred weight-gradient partials do not match the parameter they arrived for")
+        any_sum = any(pr is not None for pr in parts)
         table = torch.tensor([[grads[i].data_ptr() for i in idx], [base + 4 * self.offsets[i] for i in idx],
-                              [self.numels[i] for i in idx], prefix[:-1]], dtype=torch.int64)
+                              [self.numels[i] for i in idx], prefix[:-1],
+                              [1 if pr is None else pr[0] for pr in parts], [0 if pr is None else pr[1] for pr in parts]], dtype=torch.int64)
         if torch.cuda.is_current_stream_capturing():
             # a captured host->device copy re-reads its HOST source on every replay: give this capture its own pinned table,
             # alive as long as the plan (the ring below is overwritten by later eager steps); the pointers it holds are the
@@ -161,7 +181,7 @@ class _CastPlan:
             if not spares:
                 raise RuntimeError("fused gradient cast: run one eager backward before capturing (pinned tables are allocated there)")
             host = spares.pop()                                  # pinned memory cannot be allocated while capturing
-            dev = torch.empty((4, len(self.numels)), dtype=torch.int64, device=self.device)
+            dev = torch.empty((6, len(self.numels)), dtype=torch.int64, device=self.device)
             self.__dict__.setdefault("_capture_tables", []).append((host, dev))
             host[:, :n] = table
             dev.copy_(host, non_blocking=True)
@@ -169,10 +189,10 @@ class _CastPlan:
             ring = self.__dict__.get("_ring")
             if ring is None:
                 cap = len(self.numels)
-                ring = self._ring = {"host": [torch.empty((4, cap), dtype=torch.int64).pin_memory() for _ in range(8)],
-                                     "dev": [torch.empty((4, cap), dtype=torch.int64, device=self.device) for _ in range(8)],
+                ring = self._ring = {"host": [torch.empty((6, cap), dtype=torch.int64).pin_memory() for _ in range(8)],
+                                     "dev": [torch.empty((6, cap), dtype=torch.int64, device=self.device) for _ in range(8)],
                                      "event": [None] * 8, "next": 0}
-                self._capture_spares = [torch.empty((4, cap), dtype=torch.int64).pin_memory() for _ in range(4)]
+                self._capture_spares = [torch.empty((6, cap), dtype=torch.int64).pin_memory() for _ in range(4)]
             k = ring["next"]
             ring["next"] = (k + 1) % 8
             if ring["event"][k] is not None:
@@ -183,8 +203,13 @@ class _CastPlan:
             ev = ring["event"][k] = torch.cuda.Event()
             ev.record()
         # the last prefix entry (the total) is passed by value; the kernel's search never reads chunk_prefix[n]
-        check(lib().ocpg_multi_cast(dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), dev[3].data_ptr(), n, prefix[-1],
-                                    _DT[self.low_dtype], 0, torch.cuda.current_stream().cuda_stream), "ocpg_multi_cast")
+        if any_sum:
+            check(lib().ocpg_multi_cast_sum(dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), dev[3].data_ptr(), dev[4].data_ptr(),
+                                            dev[5].data_ptr(), n, prefix[-1], _DT[self.low_dtype], 0, torch.cuda.current_stream().cuda_stream),
+                  "ocpg_multi_cast_sum")
+        else:
+            check(lib().ocpg_multi_cast(dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), dev[3].data_ptr(), n, prefix[-1],
+                                        _DT[self.low_dtype], 0, torch.cuda.current_stream().cuda_stream), "ocpg_multi_cast")
         return [flat.as_strided(self.shapes[i], self.strides[i], self.offsets[i]) for i in idx]
 
 
@@ -234,6 +259,9 @@ class FusedCast(torch.autograd.Function):
                 torch._foreach_copy_(outs, [grads[i] for i in slow])
                 for i, o in zip(slow, outs):
                     res[i] = o
+        if _PARTIALS:       # a deferred partial sum that did not come back through the one-launch cast would silently lose slices
+            _PARTIALS.clear()
+            raise RuntimeError("deferred weight-gradient partials were not consumed by the fused gradient cast")
         return (None, None, *res)
 
 

@@ -19,6 +19,15 @@ _CL = torch.channels_last
 EPILOGUE = os.environ.get("OCPG_GEMM_EPILOGUE", "1") != "0"     # A/B switch: BN affine / skip / ReLU in the GEMM epilogue
 
 
+def _reduce_partials(part, w_is_cast_copy):
+    """[S, Co, K] row-split partial products of a weight gradient -> their sum; for the working copy of a parameter (used once per
+    forward: every ResNet convolution) the sum is left to the fused gradient cast at the end of the backward (amp_cache.defer_sum)."""
+    from ... import amp_cache
+    if w_is_cast_copy and amp_cache.DEFER_SUM and amp_cache.MULTI_CAST and part.dtype in (torch.bfloat16, torch.float16):
+        return amp_cache.defer_sum(part)
+    return part.sum(0)
+
+
 def eligible(x, conv):
     return (x.is_cuda and x.dim() == 4 and x.dtype in _DT and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)
             and conv.groups == 1 and conv.bias is None and x.is_contiguous(memory_format=_CL))
@@ -91,7 +100,7 @@ class Conv1x1BNAct(Function):
                     part = torch.empty((splits, co, c), dtype=x.dtype, device=x.device)
                     rc = L.ocpg_gemm(gz.data_ptr(), x.data_ptr(), part.data_ptr(), None, dt, dt, 1, 0, co, c, r, co, c, c, splits, r * co, r * c,
                                      co * c, 1.0, 0.0, st)
-                    gw = part.sum(0)
+                    gw = _reduce_partials(part, ctx.w_cast)
                 else:
                     gw = torch.empty((co, c), dtype=x.dtype, device=x.device)
                     rc = L.ocpg_gemm(gz.data_ptr(), x.data_ptr(), gw.data_ptr(), None, dt, dt, 1, 0, co, c, m, co, c, c, 1, 0, 0, 0, 1.0, 0.0, st)
@@ -252,7 +261,7 @@ class Conv3x3MfmaBNAct(Function):
                     part = torch.empty((splits, co, k), dtype=y.dtype, device=y.device)
                     check(L.ocpg_gemm(gz.data_ptr(), cols.data_ptr(), part.data_ptr(), None, 1, 1, 1, 0, co, k, r, co, k, k, splits, r * co, r * k,
                                       co * k, 1.0, 0.0, st), "ocpg_gemm")
-                    g2 = part.sum(0)
+                    g2 = _reduce_partials(part, ctx.w_cast)
                 else:
                     g2 = torch.empty((co, k), dtype=y.dtype, device=y.device)
                     check(L.ocpg_gemm(gz.data_ptr(), cols.data_ptr(), g2.data_ptr(), None, 1, 1, 1, 0, co, k, m, co, k, k, 1, 0, 0, 0, 1.0, 0.0, st),
