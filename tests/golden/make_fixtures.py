@@ -24,6 +24,8 @@ source text is stored.  Fixture <-> reference map:
                    norm, post-step parameters; ckpt_ref.pth = a checkpoint written by util.misc.save_on_master (main.py:229-236)
   swin_n392        WindowAttention3D at the full (8,7,7) window, N = 392 (config #5), head_dim 32, with shift mask
   swin3d           Video-Swin pieces (video_swin_transformer.py) -- see gen_swin3d
+  infer_collate    util.misc.collate_fn & friends (util/misc.py:299-379) and the per-video core of inference_davis.py:203-261, whose
+                   statements are read from the reference checkout and executed at generation time
 """
 import json
 import os
@@ -710,6 +712,86 @@ def gen_clip_transforms():
     save("clip_transforms", meta, **arrays)
 
 
+def _ref_lines(path, start_marker, end_marker):
+    """The statements of a reference script between two marker lines (inclusive of the end line), dedented -- read from the
+    reference checkout at GENERATION time and executed here; no reference text is written anywhere."""
+    import textwrap
+    lines = open(os.path.join(ref_import.REF, path)).read().split("\n")
+    a = next(i for i, ln in enumerate(lines) if start_marker in ln)
+    b = next(i for i, ln in enumerate(lines) if end_marker in ln and i > a)
+    return textwrap.dedent("\n".join(lines[a:b + 1]))
+
+
+def gen_infer_collate():
+    """Rows f3 / f4 of SURVEY section 8, pinned to the reference's OWN statements:
+      collate_*   util.misc.collate_fn / nested_tensor_from_videos_list / nested_tensor_from_tensor_list (util/misc.py:299-379) on
+                  ragged clips;
+      infer_*     the per-video core of inference_davis.py (:203-250: clip chopping, model call on a frame list, best-query
+                  selection, un-pad, resize to the original size, sigmoid, concatenation) and its multi-object merge (:254-261),
+                  EXECUTED from the reference file on JPEG frames written to a temporary folder, with the tiny reference model."""
+    import contextlib
+    import tempfile
+    import types
+    from PIL import Image
+    ref_import.install()
+    import util.misc as rmisc
+    arrays, meta = {}, {}
+    # ---- f4: collate ----------------------------------------------------------------------------------------------------
+    sizes = [(2, 3, 20, 30), (3, 3, 33, 17), (1, 3, 32, 64)]
+    clips = [synth.rand(f"col_clip{i}", s) for i, s in enumerate(sizes)]
+    targets = [{"k": i} for i in range(len(clips))]
+    samples, tg = rmisc.collate_fn(list(zip(clips, targets)))
+    assert [t["k"] for t in tg] == [0, 1, 2]
+    arrays["collate_tensors"], arrays["collate_mask"] = samples.tensors, samples.mask
+    flat = [synth.rand(f"col_img{i}", s) for i, s in enumerate([(6, 10, 12), (3, 9, 14), (9, 11, 5)])]       # [T*3, h, w] stacks
+    nt = rmisc.nested_tensor_from_tensor_list(flat, size_divisibility=8, split=True)
+    arrays["split_tensors"], arrays["split_mask"] = nt.tensors, nt.mask
+    nt1 = rmisc.nested_tensor_from_videos_list(clips[:2], size_divisibility=1)
+    arrays["nodiv_tensors"], arrays["nodiv_mask"] = nt1.tensors, nt1.mask
+    meta["collate_sizes"] = sizes
+    meta["split_sizes"] = [(6, 10, 12), (3, 9, 14), (9, 11, 5)]
+    # ---- f3: inference core -------------------------------------------------------------------------------------------
+    args, cfg, model, crit, full = build_tiny(B=1, dataset_file="davis")
+    model.eval()
+    g = torch.Generator().manual_seed(123)
+    video_len, crop_len, oh, ow, th, tw = 5, 2, 320, 400, 160, 200
+    mean, std = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1), torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
+
+    def transform(img):         # the caller's side (torchvision Resize + ToTensor + Normalize in the reference): PIL bilinear here
+        img = img.resize((tw, th), Image.BILINEAR)
+        x = torch.from_numpy(np.asarray(img).copy()).permute(2, 0, 1).float() / 255.0
+        return (x - mean) / std
+    objs_logits, objs_masks, inputs = [], [], None
+    with tempfile.TemporaryDirectory() as img_folder:
+        video_name = "vid"
+        os.makedirs(os.path.join(img_folder, video_name))
+        frames = ["%05d" % i for i in range(video_len)]
+        for f in frames:
+            px = (torch.rand(oh // 8, ow // 8, 3, generator=g) * 255).to(torch.uint8).numpy()
+            Image.fromarray(px).resize((ow, oh), Image.BICUBIC).save(os.path.join(img_folder, video_name, f + ".jpg"), quality=95)
+        inputs = torch.stack([transform(Image.open(os.path.join(img_folder, video_name, f + ".jpg")).convert("RGB")) for f in frames])
+        clip_loop = _ref_lines("inference_davis.py", "# 3. for each clip", "all_pred_masks = torch.cat(all_pred_masks, dim=0)")
+        for obj_id in range(2):         # two "objects" = two expressions (two primed text stand-ins)
+            tf, ts, tm = tiny_text(1)
+            model.text_encoder.primed = (tf * (1.0 + 0.5 * obj_id), ts * (1.0 - 0.3 * obj_id), tm)
+            ns = dict(video_len=video_len, crop_len=crop_len, frames=frames, img_folder=img_folder, video_name=video_name, transform=transform,
+                      args=types.SimpleNamespace(device="cpu", amp=False), model=model, exp="a thing", obj_id=obj_id,
+                      autocast=lambda enabled: contextlib.nullcontext(), torch=torch, F=torch.nn.functional, os=os, Image=Image,
+                      all_pred_logits=[], all_pred_masks=[])
+            exec(compile(clip_loop, "inference_davis.py[clip loop]", "exec"), ns)
+            objs_logits.append(ns["all_pred_logits"])
+            objs_masks.append(ns["all_pred_masks"])
+            arrays[f"infer_logits{obj_id}"], arrays[f"infer_masks{obj_id}"] = ns["all_pred_logits"], ns["all_pred_masks"]
+    merge = _ref_lines("inference_davis.py", "# handle a complete image", "out_masks = torch.argmax(anno_masks, dim=0)")
+    ns = dict(anno_logits=objs_logits, anno_masks=[m.clone() for m in objs_masks], torch=torch, args=types.SimpleNamespace(device="cpu"))
+    exec(compile(merge, "inference_davis.py[merge]", "exec"), ns)
+    arrays["infer_labels"] = ns["out_masks"].to(torch.uint8)
+    arrays["infer_frames"] = inputs
+    meta.update(cfg=cfg, seed=1, state_shapes=full, float_shapes=synth.shapes_of(model), video_len=video_len, crop_len=crop_len,
+                origin=[oh, ow], frame_size=[th, tw], text_scale=[[1.0, 1.0], [1.5, 0.7]])
+    save("infer_collate", meta, **arrays)
+
+
 GENS = {"msda_testpy": gen_msda_testpy, "msda_cases": gen_msda_cases, "msda_module": gen_msda_module,
         "transformer": gen_transformer, "lfm": gen_lfm, "fusion": gen_fusion, "dynmask_mso": gen_dynmask_mso,
         "matcher_crit": gen_matcher_crit, "e2e_tiny": gen_e2e_tiny, "e2e_d32": gen_e2e_d32, "e2e_cfg1": gen_e2e_cfg1,
@@ -718,6 +800,7 @@ GENS = {"msda_testpy": gen_msda_testpy, "msda_cases": gen_msda_cases, "msda_modu
         "msda_module_d32": lambda: gen_msda_module("msda_module_d32", M=2),
         "transformer_d32": lambda: gen_transformer("transformer_d32", nhead=2),
         "fusion_d32": lambda: gen_fusion("fusion_d32", nhead=2),
+        "infer_collate": gen_infer_collate,
         "swin3d": gen_swin3d, "swin_n392": gen_swin_n392, "e2e_swin": gen_e2e_swin, "clip_transforms": gen_clip_transforms}
 
 if __name__ == "__main__":

@@ -214,3 +214,42 @@ def check_reference_checkpoint(g, device):
     assert all(abs(a - b) <= 1e-6 * abs(b) + 1e-12 for a, b in zip(got, meta["exp_avg_abs_sum"]))
     assert sched.last_epoch == meta["last_epoch"]
     assert all(abs(a["lr"] - b) <= 1e-15 for a, b in zip(opt.param_groups, meta["lrs_after_resume"])), ([g_["lr"] for g_ in opt.param_groups], meta["lrs_after_resume"])
+
+
+def check_collate(g):
+    """util/misc.py:299-379 on ragged clips, against tensors produced by the reference's own functions (infer_collate.npz)."""
+    from ocpg_amd.util import misc
+    m = g.meta
+    clips = [synth.rand(f"col_clip{i}", tuple(s)) for i, s in enumerate(m["collate_sizes"])]
+    samples, tg = misc.collate_fn(list(zip(clips, [{"k": i} for i in range(len(clips))])))
+    assert [t["k"] for t in tg] == [0, 1, 2] and isinstance(tg, tuple)
+    assert torch.equal(samples.tensors, g["collate_tensors"]) and torch.equal(samples.mask, g["collate_mask"])
+    assert misc.mask_key(samples.mask) is not None          # the collate step declares every frame's valid extent
+    flat = [synth.rand(f"col_img{i}", tuple(s)) for i, s in enumerate(m["split_sizes"])]
+    nt = misc.nested_tensor_from_tensor_list(flat, size_divisibility=8, split=True)
+    assert torch.equal(nt.tensors, g["split_tensors"]) and torch.equal(nt.mask, g["split_mask"])
+    nt1 = misc.nested_tensor_from_videos_list(clips[:2], size_divisibility=1)
+    assert torch.equal(nt1.tensors, g["nodiv_tensors"]) and torch.equal(nt1.mask, g["nodiv_mask"])
+
+
+def check_inference_loop(g, device, atol_logits=1e-4, atol_masks=1e-4, label_mismatch=0.0):
+    """inference.segment_video + merge_objects against the outputs of the reference's own inference_davis.py:203-261 statements
+    (two expressions of one 5-frame video, clips of 2 + 2 + 1 frames, 160 x 200 frames -> padded 160 x 224 -> 320 x 400 masks)."""
+    from ocpg_amd import inference
+    from ocpg_amd.models.text_encoder.text_encoder import PrecomputedText
+    m = g.meta
+    args, model, _ = build_product(m, device)
+    frames = g["infer_frames"].to(device)
+    f, s, pm = cases.tiny_text(1)
+    masks = []
+    for obj, (a, b) in enumerate(m["text_scale"]):
+        text = PrecomputedText((f * a).to(device), (s * b).to(device), pm.to(device))
+        logits, mk = inference.segment_video(model, frames, text, clip_len=m["crop_len"], origin_size=tuple(m["origin"]))
+        assert logits.shape == g[f"infer_logits{obj}"].shape and mk.shape == g[f"infer_masks{obj}"].shape
+        el = (logits.float().cpu() - g[f"infer_logits{obj}"]).abs().max().item()
+        em = (mk.float().cpu() - g[f"infer_masks{obj}"]).abs().max().item()
+        assert el <= atol_logits and em <= atol_masks, (obj, el, em)
+        masks.append(mk.float().cpu())
+    lab = inference.merge_objects(torch.stack(masks))
+    bad = (lab != g["infer_labels"]).float().mean().item()
+    assert bad <= label_mismatch, bad

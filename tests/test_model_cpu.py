@@ -210,3 +210,13 @@ def test_video_inference_loop(golden, msda_double):
     assert lab.dtype == torch.uint8 and lab.shape == (T, 50, 70)
     ref = torch.cat([torch.full((1, T, 50, 70), 0.1), torch.where(objs < 0.3, torch.zeros_like(objs), objs)], 0).argmax(0)
     assert torch.equal(lab.long(), ref)
+
+
+def test_collate_matches_reference(golden):
+    """Row f4: collate_fn / nested_tensor_from_* == the reference's own functions on ragged clips (bit-exact)."""
+    model_checks.check_collate(golden("infer_collate"))
+
+
+def test_inference_loop_matches_reference(golden, msda_double):
+    """Row f3: the video inference loop == the reference's own inference_davis.py statements (executed at fixture time)."""
+    model_checks.check_inference_loop(golden("infer_collate"), torch.device("cpu"))

@@ -690,6 +690,14 @@ def test_token_linear_row_split_weight_gradient(dev, dtype, rows):
         assert (a - b_).abs().max().item() <= tol * b_.abs().max().item() + 1e-6
 
 
+def test_inference_loop_and_collate_match_reference(golden, dev):
+    """Rows f3 / f4 on the GPU: the video inference loop (clip chopping, best query, un-pad, resize, sigmoid, object merge) against
+    the outputs of the reference's own inference_davis.py:203-261 statements; collate against the reference's util/misc.py."""
+    model_checks.check_collate(golden("infer_collate"))
+    # mask probabilities: |d sigmoid| <= |d logit| / 4 with mask logits held to 1e-3; labels: threshold / argmax ties may flip a pixel
+    model_checks.check_inference_loop(golden("infer_collate"), dev, atol_logits=2e-4, atol_masks=5e-4, label_mismatch=1e-4)
+
+
 @pytest.mark.parametrize("tag", ["nopad", "pad"])
 def test_eval_tail_matches_reference(golden, dev, tag):
     model_checks.run_eval(golden("e2e_tiny"), tag, dev, rtol=1e-3, atol=1e-4)
