@@ -189,36 +189,61 @@ class GraphStep:
         optimizer.zero_grad(set_to_none=True)
         from ocpg_amd.models.ops.functions.fused_ln_func import GraphRng
         self.rng = GraphRng(self.x.device)                      # dropout generator state of this capture (device-resident base)
-        self.graph = torch.cuda.CUDAGraph(keep_graph=True)      # instantiated below, after the memset nodes are repaired
         # The captured step's outputs (model outputs, the 36 losses) stay referenced for the lifetime of the graph (static
         # outputs); self.check() compares a replay against an eager step before the timed region.
         self.static = {}
-        # capture on the warm-up stream: the library's hipBLASLt workspace is per (device, stream) and was allocated there
-        # (a hipMalloc inside the capture would invalidate it)
-        # N > 1: RCCL's watchdog thread may poll events while we capture; only THIS thread's unsafe calls should invalidate the capture
-        with self.rng, torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local" if world > 1 else "global"):
-            self.loss = forward_backward(model, criterion, NestedTensor(self.x.clone(), self._mask()), text, targets, amp_dtype,
-                                         self.num_boxes, keep=self.static, scaler=self.scaler)
-            self.rng.advance()          # last node of the step: the next replay draws fresh dropout masks
-        self.rng.finalize()
-        # memset nodes (torch's reduction semaphores) replay with a corrupted pattern on this ROCm: swap them for kernel nodes
-        import ctypes
-        from ocpg_amd import _lib
-        n_fixed = ctypes.c_int(0)
-        _lib.check(_lib.lib().ocpg_graph_replace_memsets(self.graph.raw_cuda_graph(), ctypes.byref(n_fixed)), "ocpg_graph_replace_memsets")
-        self.memset_nodes_replaced = n_fixed.value
-        stats = (ctypes.c_longlong * 9)()
-        _lib.check(_lib.lib().ocpg_graph_stats(self.graph.raw_cuda_graph(), stats), "ocpg_graph_stats")
-        self.graph_stats = dict(zip(("nodes", "edges", "roots", "max_out_degree", "max_in_degree", "kernel_nodes", "memset_nodes",
-                                     "memcpy_nodes", "other_nodes"), [int(v) for v in stats]))
-        cap = 4096
-        rows = (ctypes.c_longlong * (4 * cap))()
-        n_cp = _lib.lib().ocpg_graph_memcpy_nodes(self.graph.raw_cuda_graph(), rows, cap)
-        self.memcpy_nodes = [tuple(rows[4 * i:4 * i + 4]) for i in range(max(0, min(n_cp, cap)))]     # (kind, bytes, src, dst)
-        self.graph.instantiate()
+        self.memset_nodes_replaced = 0
+        self._capture(side, text, targets)
         self.grads = [p.grad for p in self.params]
         assert all(g is not None for g in self.grads), "a trainable parameter received no gradient"
         self.flat = None
+
+    def _capture(self, side, text, targets):
+        from ocpg_amd.util.misc import NestedTensor
+        self.graph = torch.cuda.CUDAGraph(keep_graph=True)      # instantiated below, after the memset nodes are repaired
+        # capture on the warm-up stream: the library's hipBLASLt workspace is per (device, stream) and was allocated there
+        # (a hipMalloc inside the capture would invalidate it)
+        # N > 1: RCCL's watchdog thread may poll events while we capture; only THIS thread's unsafe calls should invalidate the capture
+        with self.rng, torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local" if self.world > 1 else "global"):
+            self.loss = forward_backward(self.model, self.criterion, NestedTensor(self.x.clone(), self._mask()), text, targets, self.amp_dtype,
+                                         self.num_boxes, keep=self.static, scaler=self.scaler)
+            self.rng.advance()          # last node of the step: the next replay draws fresh dropout masks
+        self.rng.finalize()
+        self._repair_and_instantiate(self.graph, stats=True)
+        self.graphs = [self.graph]
+
+    def _repair_and_instantiate(self, graph, stats=False):
+        """memset nodes (torch's reduction semaphores) replay with a corrupted pattern on this ROCm: swap them for kernel nodes."""
+        import ctypes
+        from ocpg_amd import _lib
+        n_fixed = ctypes.c_int(0)
+        _lib.check(_lib.lib().ocpg_graph_replace_memsets(graph.raw_cuda_graph(), ctypes.byref(n_fixed)), "ocpg_graph_replace_memsets")
+        self.memset_nodes_replaced += n_fixed.value
+        if stats:
+            st = (ctypes.c_longlong * 9)()
+            _lib.check(_lib.lib().ocpg_graph_stats(graph.raw_cuda_graph(), st), "ocpg_graph_stats")
+            self.graph_stats = dict(zip(("nodes", "edges", "roots", "max_out_degree", "max_in_degree", "kernel_nodes", "memset_nodes",
+                                         "memcpy_nodes", "other_nodes"), [int(v) for v in st]))
+            cap = 4096
+            rows = (ctypes.c_longlong * (4 * cap))()
+            n_cp = _lib.lib().ocpg_graph_memcpy_nodes(graph.raw_cuda_graph(), rows, cap)
+            self.memcpy_nodes = [tuple(rows[4 * i:4 * i + 4]) for i in range(max(0, min(n_cp, cap)))]     # (kind, bytes, src, dst)
+        graph.instantiate()
+
+    def replay(self):
+        for g in self.graphs:
+            g.replay()
+        self.rng.replayed()
+
+    def replay_and_reduce(self):
+        """One step's forward + criterion + backward, gradients averaged over the ranks.  Single graph: ONE flat all-reduce after the
+        replay (not overlapped; SegmentedGraphStep overlaps)."""
+        self.replay()
+        if self.world > 1:
+            flat = torch._utils._flatten_dense_tensors(self.grads)
+            dist.all_reduce(flat)
+            flat.div_(self.world)
+            torch._foreach_copy_(self.grads, list(torch._utils._unflatten_dense_tensors(flat, self.grads)))
 
     def _encode_text(self):
         dev = next(self.model.parameters()).device
@@ -234,8 +259,7 @@ class GraphStep:
     def check(self, eager_loss, rtol=0.25):
         """One replay (no optimizer step) against the eager loss of the warm-up steps: finite, same ballpark (dropout
         masks differ), every gradient finite."""
-        self.graph.replay()
-        self.rng.replayed()
+        self.replay()
         torch.cuda.synchronize()
         loss = float(self.loss)
         # (fp16: a replay at the initial loss scale may overflow -- that is the scaler's business, not a capture failure)
@@ -254,16 +278,10 @@ class GraphStep:
                 dst.copy_(src)
         if self.fence:
             torch.cuda.synchronize()
-        self.graph.replay()
-        self.rng.replayed()
+        self.replay_and_reduce()
         if self.fence:
             torch.cuda.synchronize()
         self.criterion.iter_device += self.calls_per_fwd
-        if self.world > 1:
-            flat = torch._utils._flatten_dense_tensors(self.grads)
-            dist.all_reduce(flat)
-            flat.div_(self.world)
-            torch._foreach_copy_(self.grads, list(torch._utils._unflatten_dense_tensors(flat, self.grads)))
         if self.scaler is not None:
             self.scaler.unscale_(self.optimizer)
         if self.args.clip_max_norm > 0:
@@ -274,6 +292,153 @@ class GraphStep:
         else:
             self.optimizer.step()
         return self.loss
+
+
+class SegmentedGraphStep(GraphStep):
+    """The captured step cut into THREE graphs at two points of the ResNet backward, so that the gradient all-reduce of one part
+    overlaps the backward of the next (main.py:62's DistributedDataParallel overlaps bucket by bucket; a single captured graph
+    cannot: its gradients only exist when the replay ends):
+        G1  forward + criterion + backward of everything behind the backbone      -> all-reduce bucket 0 (neck, transformer, heads)
+        G2  backward of layer4 and the later half of layer3                        -> all-reduce bucket 1   | while G2 / G3 run
+        G3  backward of the first half of layer3 and of layer2                     -> all-reduce bucket 2   (the only exposed one)
+    Each part's autocast parameters have their OWN fused-cast node (amp_cache.set_groups), so their fp32 gradients are born as views
+    of ONE flat buffer per part: the buckets are those buffers themselves (no flatten / copy-back), plus one small flattened
+    remainder for parameters outside the cast (fp32 islands).  ResNet backbones, no GradScaler; anything else keeps GraphStep."""
+
+    SPLIT = 10          # layer3 blocks [0, SPLIT) belong to G3, [SPLIT, 23) to G2 (ResNet-101: ~12 M / ~29 M backbone parameters)
+
+    @staticmethod
+    def supported(model, amp_dtype):
+        body = getattr(model.backbone[0], "body", None)
+        return amp_dtype == torch.bfloat16 and body is not None and all(hasattr(body, f"layer{i}") for i in (2, 3, 4)) and len(body.layer3) >= 2
+
+    def __init__(self, model, criterion, optimizer, make_samples, text, targets, args, amp_dtype, world):
+        from ocpg_amd.models import amp_cache
+        body = model.backbone[0].body
+        k = min(self.SPLIT, len(body.layer3) - 1)
+
+        def group_of(n):     # 0 behind the backbone | 1 layer4 | 2 layer3[k:] | 3 layer3[:k] | 4 layer2 (and the frozen stem / layer1)
+            if not n.startswith("backbone.0.body."):
+                return 0
+            q = n.split(".")
+            if q[3] == "layer4":
+                return 1
+            if q[3] == "layer3":
+                return 2 if int(q[4]) >= k else 3
+            return 4
+        self.group_of = group_of
+        amp_cache.set_groups(model, group_of)       # one fused-cast node (one flat gradient buffer) per part: see _capture
+        self.cut_modules = (("f8", body.layer2), ("mid", body.layer3[k - 1]), ("f16", body.layer3), ("f32", body.layer4))
+        self.split_k = k
+        super().__init__(model, criterion, optimizer, make_samples, text, targets, args, amp_dtype, world)
+
+    def _capture(self, side, text, targets):
+        from ocpg_amd.util.misc import NestedTensor
+        model, criterion = self.model, self.criterion
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        P = [[p for n, p in named if self.group_of(n) == i] for i in range(5)]
+        # The backward is CUT at four activations: in the captured forward each of them is replaced by a detached leaf (the module's
+        # forward hook returns it), so the sub-graphs on either side are disjoint and `autograd.grad` over one of them neither needs
+        # nor runs the other (without the cut, d loss / d f8 is a TOTAL derivative: autograd would run layer3 and layer4 to deliver it).
+        orig, leaf = {}, {}
+
+        def cut(key):
+            def hook(mod, inp, out):
+                orig[key] = out
+                leaf[key] = out.detach().requires_grad_(True)
+                return leaf[key]
+            return hook
+        self.hooks = [m.register_forward_hook(cut(key)) for key, m in self.cut_modules]
+        mode = "thread_local" if self.world > 1 else "global"
+        self.graphs = [torch.cuda.CUDAGraph(keep_graph=True) for _ in range(3)]
+        st = self.static
+        grad = torch.autograd.grad
+        with self.rng:
+            with torch.cuda.graph(self.graphs[0], stream=side, capture_error_mode=mode):
+                with torch.autocast(device_type=self.x.device.type, dtype=self.amp_dtype):
+                    out = model(NestedTensor(self.x.clone(), self._mask()), text, targets)
+                    out["num_boxes"] = self.num_boxes
+                    loss_dict, *_ = criterion(out, targets)
+                    loss = criterion.weighted_sum(loss_dict)
+                g = grad(loss, P[0] + [leaf["f8"], leaf["f16"], leaf["f32"]])
+                st["g0"], (g8, g16, g32) = list(g[:len(P[0])]), g[len(P[0]):]
+                st.update(out=out, loss_dict=loss_dict, loss=loss, orig=orig, leaf=leaf, gb=(g8, g16, g32))
+            pool = self.graphs[0].pool()
+            with torch.cuda.graph(self.graphs[1], stream=side, pool=pool, capture_error_mode=mode):
+                g = grad(orig["f32"], P[1] + [leaf["f16"]], grad_outputs=g32)                     # layer4
+                g_l4, g16_l4 = list(g[:-1]), g[-1]
+                g = grad(orig["f16"], P[2] + [leaf["mid"]], grad_outputs=g16 + g16_l4)            # layer3[k:]  (f16 feeds the neck AND layer4)
+                st["g1"], gmid = g_l4 + list(g[:-1]), g[-1]
+            with torch.cuda.graph(self.graphs[2], stream=side, pool=pool, capture_error_mode=mode):
+                g = grad(orig["mid"], P[3] + [leaf["f8"]], grad_outputs=gmid)                     # layer3[:k]
+                g_l3a, g8_l3 = list(g[:-1]), g[-1]
+                st["g2"] = g_l3a + list(grad(orig["f8"], P[4], grad_outputs=g8 + g8_l3))           # layer2  (f8 feeds the neck AND layer3)
+                self.rng.advance()      # last node of the step: the next replay draws fresh dropout masks
+        seg_params = [P[0], P[1] + P[2], P[3] + P[4]]
+        self.rng.finalize()
+        for h in self.hooks:
+            h.remove()
+        for i, gr in enumerate(self.graphs):
+            self._repair_and_instantiate(gr, stats=(i == 0))
+        self.loss = loss.detach()
+        for ps, gs in zip(seg_params, (st["g0"], st["g1"], st["g2"])):
+            for p_, g_ in zip(ps, gs):
+                p_.grad = g_            # static tensors of the graphs' pool: every replay refills them
+        self.buckets = self.build_buckets((st["g0"], st["g1"], st["g2"]), self.x.device)
+        self.bucket_bytes = [4 * (sum(b.numel() for b in bk["dense"]) + (bk["small"].numel() if bk["small"] is not None else 0)) for bk in self.buckets]
+
+    @staticmethod
+    def build_buckets(grad_lists, device):
+        """One all-reduce bucket per segment: the flat fp32 buffers the segment's fused cast wrote its gradients into ("dense": reduced
+        in place, no copies) + one flattened remainder for the gradients that are not views of such a buffer ("rest" -> "small")."""
+        buckets = []
+        for gs in grad_lists:
+            bases, members, rest = {}, {}, []
+            for g_ in gs:
+                b = g_._base
+                if b is not None and b.dim() == 1 and b.dtype == torch.float32 and b.is_contiguous():
+                    bases[b.data_ptr()] = b
+                    members[b.data_ptr()] = members.get(b.data_ptr(), 0) + g_.numel()
+                else:
+                    rest.append(g_)
+            dense = []
+            for ptr, b in bases.items():
+                if 2 * members[ptr] >= b.numel():
+                    dense.append(b)
+                else:           # mostly gaps (does not happen with one cast group per segment): its members go one by one
+                    rest += [g_ for g_ in gs if g_._base is b]
+            small = torch.empty(sum(g_.numel() for g_ in rest), dtype=torch.float32, device=device) if rest else None
+            views = [v.view_as(g_) for v, g_ in zip(small.split([g_.numel() for g_ in rest]), rest)] if rest else []
+            buckets.append({"dense": dense, "rest": rest, "small": small, "views": views})
+        return buckets
+
+    def _reduce_async(self, bk):
+        works = []
+        avg = dist.get_backend() == "nccl"              # RCCL averages inside the collective; gloo (rehearsal) sums, divided below
+        op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+        if bk["small"] is not None:
+            torch._foreach_copy_(bk["views"], bk["rest"])
+            works.append(dist.all_reduce(bk["small"], op=op, async_op=True))
+        for b in bk["dense"]:
+            works.append(dist.all_reduce(b, op=op, async_op=True))
+        return works
+
+    def replay_and_reduce(self):
+        works = []
+        for g, bk in zip(self.graphs, self.buckets):
+            g.replay()
+            if self.world > 1:
+                works += self._reduce_async(bk)         # runs on the process group's stream, behind this replay, beside the next one
+        self.rng.replayed()
+        if self.world > 1:
+            for w in works:
+                w.wait()
+            if dist.get_backend() != "nccl":
+                torch._foreach_div_([b for bk in self.buckets for b in bk["dense"]] + [bk["small"] for bk in self.buckets if bk["small"] is not None],
+                                    float(self.world))
+            for bk in self.buckets:
+                if bk["small"] is not None:
+                    torch._foreach_copy_(bk["rest"], bk["views"])
 
 
 def time_msda_kernels(n_frames, device, iters=20, noise=0.0, outliers=0.0):
@@ -528,11 +693,15 @@ def main():
             eager_loss = float(forward_backward(model, criterion, make_samples(), text, targets, amp_dtype))
             model.zero_grad(set_to_none=True)
             criterion.iter = 0
-            step = GraphStep(model, criterion, optimizer, make_samples, text, targets, args, amp_dtype, world)
+            seg = os.environ.get("OCPG_GRAPH_SEGMENTS", "auto")      # auto: three graphs with overlapped all-reduces when N > 1
+            use_seg = SegmentedGraphStep.supported(model, amp_dtype) and (seg == "3" or (seg == "auto" and world > 1))
+            step = (SegmentedGraphStep if use_seg else GraphStep)(model, criterion, optimizer, make_samples, text, targets, args, amp_dtype, world)
             step.check(eager_loss)                               # one replay, no collective
         except Exception as e:      # capture is an optimisation, never a requirement: report and run eagerly
-            print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {str(e)[:200]}); running eagerly", file=sys.stderr, flush=True)
+            print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {str(e)[:400]}); running eagerly", file=sys.stderr, flush=True)
             torch.cuda.synchronize()
+            from ocpg_amd.models import amp_cache
+            amp_cache._PARTIALS.clear()         # an aborted backward may leave deferred partial sums registered
             ok, step = 0, None
         if world > 1:               # the launch mode must be the same on every rank (graph: one flat all-reduce; eager: DDP buckets)
             flag = torch.tensor([ok], dtype=torch.int32, device=device)
@@ -636,7 +805,10 @@ def main():
         "final_loss": float(loss.detach()),
     }
     if mode != "eager":
-        line["hipgraph"] = {"memset_nodes_replaced_by_kernel_nodes": step.memset_nodes_replaced, "checked_against_eager": True}
+        line["hipgraph"] = {"memset_nodes_replaced_by_kernel_nodes": step.memset_nodes_replaced, "checked_against_eager": True,
+                            "graphs": len(step.graphs)}
+        if hasattr(step, "bucket_bytes"):
+            line["hipgraph"]["allreduce_buckets_bytes"] = step.bucket_bytes       # bucket i is reduced while graph i + 1 replays
     line["ranks"] = {"world_size": dist.get_world_size() if world > 1 else 1, "backend": dist.get_backend() if world > 1 else None}
     import ctypes
     changed = ctypes.c_longlong(0)

@@ -168,7 +168,8 @@ class _CastPlan:
         parts = [_PARTIALS.pop(grads[i].data_ptr(), None) if _PARTIALS else None for i in idx]
         for i, pr in zip(idx, parts):
             if pr is not None and pr[2] != self.numels[i]:
-                raise RuntimeError("deferred weight-gradient partials do not match the parameter they arrived for")
+                raise RuntimeError(f"deferred weight-gradient partials do not match the parameter they arrived for: parameter {i} of shape "
+                                   f"{self.shapes[i]}, gradient {tuple(grads[i].shape)}, partials {pr}")
         any_sum = any(pr is not None for pr in parts)
         table = torch.tensor([[grads[i].data_ptr() for i in idx], [base + 4 * self.offsets[i] for i in idx],
                               [self.numels[i] for i in idx], prefix[:-1],
@@ -259,9 +260,6 @@ class FusedCast(torch.autograd.Function):
                 torch._foreach_copy_(outs, [grads[i] for i in slow])
                 for i, o in zip(slow, outs):
                     res[i] = o
-        if _PARTIALS:       # a deferred partial sum that did not come back through the one-launch cast would silently lose slices
-            _PARTIALS.clear()
-            raise RuntimeError("deferred weight-gradient partials were not consumed by the fused gradient cast")
         return (None, None, *res)
 
 
@@ -494,30 +492,61 @@ def register(module, *params):
     module._amp_cache_extra = tuple(params)
 
 
+def set_groups(module, group_of):
+    """Partition the fused cast of `module` into several FusedCast nodes: group_of(parameter name) -> int.  One node per group means
+    one flat gradient buffer per group and -- what the segmented multi-GPU step of bench.py needs -- a backward pass restricted to
+    some parameters no longer drags every layer that feeds the (single) cast node along.  None / never called: one group."""
+    if group_of is None:
+        module.__dict__.pop("_amp_cache_group_of", None)
+    else:
+        module.__dict__["_amp_cache_group_of"] = group_of
+    module.__dict__.pop("_amp_cache_params", None)
+    module.__dict__.pop("_amp_cache_plans", None)
+
+
+def _param_groups(module):
+    groups = module.__dict__.get("_amp_cache_params")
+    if groups is None:
+        params = cast_params_of(module)
+        group_of = module.__dict__.get("_amp_cache_group_of")
+        if group_of is None:
+            groups = [params]
+        else:
+            names = {id(p): n for n, p in module.named_parameters()}
+            by = {}
+            for p in params:
+                by.setdefault(int(group_of(names.get(id(p), ""))), []).append(p)
+            groups = [by[k] for k in sorted(by)]
+        module.__dict__["_amp_cache_params"] = groups
+    return groups
+
+
 @contextlib.contextmanager
 def scope(module):
     """Inside: `lookup(p)` returns this forward's low-precision copy of p (when autocast is on for the GPU)."""
-    params = None
+    groups = None
     if ENABLED and torch.is_autocast_enabled("cuda"):
-        params = module.__dict__.get("_amp_cache_params")
-        if params is None:
-            params = module.__dict__["_amp_cache_params"] = cast_params_of(module)
-        params = [p for p in params if p.is_cuda]
-    if not params:
+        groups = [[p for p in g if p.is_cuda] for g in _param_groups(module)]
+        groups = [g for g in groups if g]
+    if not groups:
         yield
         return
+    if _PARTIALS:       # a deferred partial sum of the LAST backward that did not come back through a one-launch cast lost its slices
+        _PARTIALS.clear()
+        raise RuntimeError("deferred weight-gradient partials were not consumed by the fused gradient cast")
     low = torch.get_autocast_dtype("cuda")
-    plan = None
-    if MULTI_CAST and low in (torch.bfloat16, torch.float16):
-        plans = module.__dict__.setdefault("_amp_cache_plans", {})
-        ptrs = [p.data_ptr() for p in params]
-        plan = plans.get(low)
-        if plan is None or plan.src_ptrs_host != ptrs:      # first use, or parameters (re)allocated (.to(), memory format, ...)
-            plan = plans[low] = _CastPlan(params, low) if all(_dense(p) and p.dtype == torch.float32 for p in params) else _NoPlan(ptrs)
-        if isinstance(plan, _NoPlan):
-            plan = None
-    outs = FusedCast.apply(low, plan, *params)
-    _ACTIVE.update({id(p): o for p, o in zip(params, outs)})
+    for gi, params in enumerate(groups):
+        plan = None
+        if MULTI_CAST and low in (torch.bfloat16, torch.float16):
+            plans = module.__dict__.setdefault("_amp_cache_plans", {})
+            ptrs = [p.data_ptr() for p in params]
+            plan = plans.get((low, gi))
+            if plan is None or plan.src_ptrs_host != ptrs:      # first use, or parameters (re)allocated (.to(), memory format, ...)
+                plan = plans[(low, gi)] = _CastPlan(params, low) if all(_dense(p) and p.dtype == torch.float32 for p in params) else _NoPlan(ptrs)
+            if isinstance(plan, _NoPlan):
+                plan = None
+        outs = FusedCast.apply(low, plan, *params)
+        _ACTIVE.update({id(p): o for p, o in zip(params, outs)})
     try:
         yield
     finally:

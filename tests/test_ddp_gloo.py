@@ -243,3 +243,76 @@ def test_num_boxes_allreduce():
     for rank, got, want, nb in res:
         assert nb == 2.0
         assert abs(got - want) <= 1e-6 * abs(want)
+
+
+class _FakeGraph:
+    """CPU stand-in for one captured segment: a replay refills the segment's STATIC gradient tensors in place."""
+
+    def __init__(self, fill):
+        self.fill = fill
+
+    def replay(self):
+        self.fill()
+
+
+def _seg_worker(rank, world, port, q):
+    _setup_paths()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    g = torch.Generator().manual_seed(7)
+    shapes = [[(4, 3), (5,), (2, 2, 2)], [(6,), (3, 3)], [(7, 2)]]             # three segments of "parameters"
+    loose = [[(3,)], [], [(2, 5), (1,)]]                                        # gradients that are NOT views of a flat cast buffer
+    values = [[torch.randn(s, generator=g) for s in seg + lo] for seg, lo in zip(shapes, loose)]      # identical on both ranks
+    grad_lists, fills = [], []
+    for seg, lo, vals in zip(shapes, loose, values):
+        n = sum(torch.Size(s).numel() + 3 for s in seg)                         # gaps between the views, like the 16-byte alignment of the plan
+        flat = torch.full((n,), float("nan"))                                   # gaps hold garbage (torch.empty in the product)
+        views, off = [], 0
+        for s in seg:
+            k = torch.Size(s).numel()
+            views.append(flat[off:off + k].view(s))
+            off += k + 3
+        singles = [torch.empty(s) for s in lo]
+        gl = views + singles
+        grad_lists.append(gl)
+
+        def fill(gl=gl, vals=vals):
+            for t, v in zip(gl, vals):
+                t.copy_(v * (rank + 1))                                          # rank r's gradient = (r + 1) * v  ->  average = 1.5 v
+        fills.append(fill)
+    step = object.__new__(bench.SegmentedGraphStep)
+    step.world = world
+    step.graphs = [_FakeGraph(f) for f in fills]
+    step.buckets = bench.SegmentedGraphStep.build_buckets(grad_lists, torch.device("cpu"))
+
+    class _Rng:
+        def replayed(self):
+            pass
+    step.rng = _Rng()
+    assert [len(b["dense"]) for b in step.buckets] == [1, 1, 1] and [len(b["rest"]) for b in step.buckets] == [1, 0, 2]
+    for _ in range(2):                                                           # two steps: the buffers are reused
+        step.replay_and_reduce()
+    err = max(float((t - 1.5 * v).abs().max()) for gl, vals in zip(grad_lists, values) for t, v in zip(gl, vals))
+    q.put((rank, err))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_segmented_graph_step_reduce_path_two_ranks():
+    """bench.py's SegmentedGraphStep (three captured graphs, bucket i all-reduced while graph i + 1 replays): its OWN bucket builder
+    and replay_and_reduce over a 2-rank gloo group, with CPU stand-ins for the replays -- every gradient (views of the flat cast
+    buffers and loose ones) ends as the average over the ranks, twice in a row."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_seg_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=200) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, err in res:
+        assert err <= 1e-6, (rank, err)

@@ -251,3 +251,73 @@ def test_dropout_masks_advance_under_replay(dev):
     y_next = f.dropout_add_layer_norm(xin, res, norm, p).detach()
     f.set_rng_state({"dropout_calls": 1009})
     assert torch.equal(y_next, f.dropout_add_layer_norm(xin, res, norm, p).detach())
+
+
+def test_segmented_graph_step_matches_single_graph(dev):
+    """bench.py's SegmentedGraphStep (three graphs cut at detached activations of the ResNet backward, one fused-cast node and one
+    flat gradient buffer per part: what N > 1 ranks replay so that all-reduces overlap the backward) against the single-graph step at
+    the same parameters: same loss, same gradients (to the eager step's own run-to-run noise), every gradient a view of its part's
+    flat buffer, and the buckets cover every trainable parameter exactly once."""
+    import copy
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests"), os.path.join(root, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import bench
+    import cases
+    import model_checks
+    from conftest import Golden
+    from ocpg_amd.models import amp_cache
+    from ocpg_amd.util.misc import NestedTensor
+    meta = Golden("e2e_d32").meta
+    args, model, crit = model_checks.build_product(meta, dev)
+    model_checks.to_channels_last(model)
+    model.train(), crit.train()
+    det_before = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        T, H, W = meta["T"], meta["H"], meta["W"]
+        x, mask, targets = cases.e2e_inputs(2, T, H, W, meta["nopad_sizes"], dev)
+        text = model_checks.text_for(2, dev)
+        make_samples = lambda: NestedTensor(x.clone(), mask.clone())      # noqa: E731
+        amp = torch.bfloat16
+        twin, twin_crit = copy.deepcopy(model), copy.deepcopy(crit)
+        # yardstick: two eager steps at identical parameters
+        runs = []
+        for _ in range(2):
+            twin.zero_grad(set_to_none=True)
+            twin_crit.iter = 0
+            bench.forward_backward(twin, twin_crit, make_samples(), text, targets, amp)
+            runs.append({k: p.grad.clone() for k, p in twin.named_parameters() if p.grad is not None})
+        noise = {k: (runs[0][k] - runs[1][k]).abs().max().item() for k in runs[0]}
+        crit.iter = 0
+        single = bench.GraphStep(model, crit, bench.make_optimizer(model, args, fused=False), make_samples, text, targets, args, amp, 1)
+        single.replay()
+        torch.cuda.synchronize()
+        want_loss = float(single.loss)
+        want = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        assert bench.SegmentedGraphStep.supported(model, amp)
+        crit.iter = 0
+        seg = bench.SegmentedGraphStep(model, crit, bench.make_optimizer(model, args, fused=False), make_samples, text, targets, args, amp, 1)
+        assert len(seg.graphs) == 3
+        for rep in range(2):
+            seg.replay()
+            torch.cuda.synchronize()
+            assert abs(float(seg.loss) - want_loss) <= 2e-3 * abs(want_loss), (rep, float(seg.loss), want_loss)
+            for k, p in model.named_parameters():
+                if k in want:
+                    d = (p.grad.float() - want[k].float()).abs().max().item()
+                    assert d <= 8 * noise[k] + 0.15 * want[k].abs().max().item() + 1e-7, (rep, k, d, noise[k])
+        # buckets: every trainable parameter's gradient is reduced exactly once
+        covered = 0
+        for bk in seg.buckets:
+            covered += sum(g.numel() for g in bk["rest"])
+            for b in bk["dense"]:
+                lo, hi = b.data_ptr(), b.data_ptr() + 4 * b.numel()
+                covered += sum(p.grad.numel() for p in seg.params if lo <= p.grad.data_ptr() < hi)
+        assert covered == sum(p.numel() for p in seg.params), (covered, sum(p.numel() for p in seg.params))
+        assert sum(len(bk["dense"]) for bk in seg.buckets) == 5           # one flat buffer per fused-cast group
+    finally:
+        torch.backends.cudnn.deterministic = det_before
+        amp_cache.set_groups(model, None)
