@@ -278,7 +278,7 @@ def test_segmented_graph_step_matches_single_graph(dev):
     torch.backends.cudnn.deterministic = True
     try:
         T, H, W = meta["T"], meta["H"], meta["W"]
-        x, mask, targets = cases.e2e_inputs(2, T, H, W, meta["nopad_sizes"], dev)
+        x, mask, targets = cases.e2e_inputs(2, T, H, W, meta["pad_sizes"], dev)
         text = model_checks.text_for(2, dev)
         make_samples = lambda: NestedTensor(x.clone(), mask.clone())      # noqa: E731
         amp = torch.bfloat16
