@@ -821,12 +821,12 @@ def main():
         if dom is not None:
             traffic = None          # HBM bytes per launch from the committed rocprofv3 --pmc passes (same shape, same kernel)
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_msda_pmc.json")))
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_msda_pmc.json")))
                 if pmc["n_frames"] == a.clips_per_gpu * T_FRAMES and (HEIGHT, WIDTH) == (384, 640):
                     traffic = pmc["k_scatter_col"]["hbm_bytes_per_launch"]
             except (OSError, KeyError, ValueError):
                 pass
-            line["roofline"] = {"bound": "hbm", "kernel": "k_scatter_col (grad_value of the MSDeformAttn backward, encoder shape, N=%d frames)"
+            line["roofline"] = {"bound": "hbm", "kernel": "k_scatter_col2 (grad_value of the MSDeformAttn backward, encoder shape, N=%d frames)"
                                                           % (a.clips_per_gpu * T_FRAMES),
                                 "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": traffic,
                                 "launch_us": dom["us"], "algorithmic_bytes": dom["algorithmic_bytes"],

@@ -26,6 +26,7 @@
 #include "msda_col.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "msda_dev.h"
 
@@ -527,12 +528,252 @@ __global__ __launch_bounds__(NT) void k_scatter_col(const float* __restrict__ lo
   }
 }
 
+// ----------------------------------------------------------------------------------------------------------------------
+// Backward-scatter, TWO destination levels per pass (round 3).  The single-level kernel above spends 5 workgroup barriers per
+// level on one sample per thread (stamps: binning 31 %, end-of-level barrier 14 %); here a pass bins the samples of a level PAIR
+// into the concatenation of their two windows: half the barriers, twice the independent LDS work between them; the list starts
+// and the compaction of the non-empty pixels come from ONE wave (12 bins per lane) instead of a two-barrier cross-wave scan, and
+// a thread's eight counter atomics / eight list writes are issued back to back (their results are first used after the last one
+// is in flight).  Same results as k_scatter_col up to the order of the fp32 sums.
+template <int G, int NT>
+__global__ __launch_bounds__(NT) void k_scatter_col2(const float* __restrict__ loc, const float* __restrict__ attn,
+                                                      const float* __restrict__ gout, int S, int M, int P, ColGeom geo,
+                                                      float* __restrict__ gvalue) {
+  constexpr int D = 4 * G, GROUPS = NT / G, BPL = NT / 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* gs = reinterpret_cast<float*>(smem);                                           // [tmax][D], channel j + G*c at 4*j + c
+  Item* items = reinterpret_cast<Item*>(smem + (size_t)geo.tmax * D * sizeof(float));    // [tmax * P * 8]
+  int* qg = reinterpret_cast<int*>(items + (size_t)geo.tmax * P * 8);                    // [tmax]
+  __shared__ int cnt[NT], start[NT], nz[NT], nnz_s;
+  __shared__ TileCtx tc;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int bid = blockIdx.x;
+  const int bt = (int)udiv(bid, M, geo.m_M);
+  const int m = bid - bt * M;
+  const int b = (int)udiv(bt, geo.ntiles, geo.m_ntiles), tile = bt - b * geo.ntiles;
+  cnt[tid] = 0;
+  tile_setup(geo, tile, tc, tid);
+  const int L = geo.L, NS = L * P, MD = M * D;
+  const int T = tc.qbase[L], TP = T * P;
+  for (int i = tid; i < T; i += NT) qg[i] = local_to_query(tc, L, i);
+  __syncthreads();
+  const int j = tid % G;
+  const int ts = min(tid, TP - 1);
+  const int qloc = (int)udiv(ts, P, geo.m_P);
+  float2 sxy[kLM];
+  float sa[kLM];
+  {
+    const int p = ts - qloc * P;
+    const long long wi0 = (((long long)b * S + qg[qloc]) * M + m) * NS + p;
+#pragma unroll
+    for (int l = 0; l < kLM; ++l) {
+      const long long wi = wi0 + min(l, L - 1) * P;
+      sxy[l] = *reinterpret_cast<const float2*>(loc + wi * 2);
+      sa[l] = attn[wi];
+    }
+  }
+  {
+    float4 gq[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int ql = min(tid / G + u * GROUPS, T - 1);
+      const float* g = gout + (((long long)b * S + qg[ql]) * M + m) * D + j;
+      gq[u] = make_float4(g[0], g[G], g[2 * G], g[3 * G]);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int ql = tid / G + u * GROUPS;
+      if (ql < T) *reinterpret_cast<float4*>(gs + ql * D + 4 * j) = gq[u];
+    }
+  }
+  __syncthreads();
+  float* gvb = gvalue + (long long)b * S * MD + m * D;
+#pragma unroll
+  for (int l0 = 0; l0 < kLM; l0 += 2) {
+    if (l0 < L) {
+      const int nl = min(2, L - l0);
+      const int wpx0 = tc.wh[l0] * tc.ww[l0];
+      const int l1c = l0 + 1 < kLM ? l0 + 1 : l0;          // known after unrolling (register arrays stay in registers); guarded by nl below
+      const int wtot2 = wpx0 + (nl > 1 ? tc.wh[l1c] * tc.ww[l1c] : 0);
+      // (1) bin both levels' samples: bins [0, wpx0) = window of level l0, [wpx0, wtot2) = window of level l0 + 1
+      int pid[8], ovm[2] = {0, 0}, opix[2] = {0, 0};
+      float wk[8];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int l = u ? l1c : l0;
+        const int H = tc.H[l], W = tc.W[l], wy0 = tc.wy0[l], wx0 = tc.wx0[l], wh = tc.wh[l], ww = tc.ww[l];
+        const int boff = u ? wpx0 : 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { pid[u * 4 + k] = -1; wk[u * 4 + k] = 0.f; }
+        if (tid < TP && u < nl) {
+          const float h_im = sxy[l].y * (float)H - 0.5f, w_im = sxy[l].x * (float)W - 0.5f;
+          if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+            const int y0 = (int)floorf(h_im), x0 = (int)floorf(w_im);
+            const float ly = h_im - (float)y0, lx = w_im - (float)x0, hy = 1.f - ly, hx = 1.f - lx, a = sa[l];
+            const bool y0ok = y0 >= 0, y1ok = y0 + 1 <= H - 1, x0ok = x0 >= 0, x1ok = x0 + 1 <= W - 1;
+            const int mask = (y0ok && x0ok ? 1 : 0) | (y0ok && x1ok ? 2 : 0) | (y1ok && x0ok ? 4 : 0) | (y1ok && x1ok ? 8 : 0);
+            wk[u * 4 + 0] = hy * hx * a; wk[u * 4 + 1] = hy * lx * a; wk[u * 4 + 2] = ly * hx * a; wk[u * 4 + 3] = ly * lx * a;
+            const bool in = max(y0, 0) >= wy0 && min(y0 + 1, H - 1) < wy0 + wh && max(x0, 0) >= wx0 && min(x0 + 1, W - 1) < wx0 + ww;
+            if (in) {
+              const int p0 = boff + (y0 - wy0) * ww + (x0 - wx0);        // may be "virtual" (row / column -1): only corners in the mask are used
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+                if (mask & (1 << k)) pid[u * 4 + k] = p0 + (k & 1) + (k >> 1) * ww;
+            } else {
+              ovm[u] = mask;
+              opix[u] = y0 * W + x0;
+            }
+          }
+        }
+      }
+      int slot[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) slot[i] = pid[i] >= 0 ? atomicAdd(&cnt[pid[i]], 1) : 0;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        // corners outside the window: straight to memory, one contribution per wave step, D lanes x 4 B contiguous
+        const int l = u ? l1c : l0;
+        const int W = tc.W[l];
+        float* gvl = gvb + (long long)tc.S0[l] * MD;
+        unsigned long long bal = __ballot(ovm[u] != 0);
+        while (bal) {
+          const int src = __ffsll((long long)bal) - 1;
+          bal &= bal - 1;
+          const int om = __builtin_amdgcn_readlane(ovm[u], src), gp = __builtin_amdgcn_readlane(opix[u], src),
+                    qs = __builtin_amdgcn_readlane(qloc, src);
+          float wsrc[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) wsrc[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wk[u * 4 + k]), src));
+          if (lane < D) {
+            const float g = gs[qs * D + 4 * (lane % G) + lane / G];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (om & (1 << k)) atomicAdd(gvl + (long long)(gp + (k & 1) + (k >> 1) * W) * MD + lane, wsrc[k] * g);
+          }
+        }
+      }
+      lds_barrier();
+      // (2) list starts + compaction of the non-empty pixels, by one wave (BPL consecutive bins per lane, packed count | flag << 16)
+      if (tid < 64) {
+        int c[BPL], s = 0;
+#pragma unroll
+        for (int i = 0; i < BPL; ++i) {
+          const int bin = lane * BPL + i;
+          c[i] = bin < wtot2 ? cnt[bin] : 0;
+          s += c[i] | (c[i] ? 1 << 16 : 0);
+        }
+        int inc = s;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int t = __shfl_up(inc, o, 64);
+          if (lane >= o) inc += t;
+        }
+        int run = inc - s;
+#pragma unroll
+        for (int i = 0; i < BPL; ++i) {
+          const int bin = lane * BPL + i;
+          start[bin] = run & 0xffff;
+          if (c[i]) nz[run >> 16] = bin;
+          run += c[i] | (c[i] ? 1 << 16 : 0);
+        }
+        if (lane == 63) nnz_s = inc >> 16;
+      }
+      lds_barrier();
+      // (3) drop the items into their lists: all starts first, then the writes
+      {
+        int st[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) st[i] = start[max(pid[i], 0)];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (pid[i] >= 0) {
+            Item it;
+            it.w = wk[i];
+            it.q = qloc * D;
+            items[st[i] + slot[i]] = it;
+          }
+      }
+      lds_barrier();
+      // (4) every touched pixel is summed in registers by the G lanes that own it, then flushed once (pairs of groups: full 64-B lines)
+      const int nnz = nnz_s;
+      for (int kk0 = (tid / (2 * G)) * 2; kk0 < nnz; kk0 += GROUPS) {
+        const int odd = (tid / G) & 1;
+        const int kk = kk0 + odd;
+        const bool valid = kk < nnz;
+        const int pp = valid ? nz[kk] : 0;
+        const int n = valid ? cnt[pp] : 0;
+        const Item* lst = items + start[pp];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int t = 0;
+        for (; t + 4 <= n; t += 4) {
+          const Item i0 = lst[t], i1 = lst[t + 1], i2 = lst[t + 2], i3 = lst[t + 3];
+          const float4 g0 = ld4(gs + i0.q + 4 * j), g1 = ld4(gs + i1.q + 4 * j), g2 = ld4(gs + i2.q + 4 * j),
+                       g3 = ld4(gs + i3.q + 4 * j);
+          acc.x += i0.w * g0.x + i1.w * g1.x + i2.w * g2.x + i3.w * g3.x;
+          acc.y += i0.w * g0.y + i1.w * g1.y + i2.w * g2.y + i3.w * g3.y;
+          acc.z += i0.w * g0.z + i1.w * g1.z + i2.w * g2.z + i3.w * g3.z;
+          acc.w += i0.w * g0.w + i1.w * g1.w + i2.w * g2.w + i3.w * g3.w;
+        }
+        for (; t < n; ++t) {
+          const Item i0 = lst[t];
+          const float4 g0 = ld4(gs + i0.q + 4 * j);
+          acc.x += i0.w * g0.x; acc.y += i0.w * g0.y; acc.z += i0.w * g0.z; acc.w += i0.w * g0.w;
+        }
+        const int u = pp >= wpx0 ? 1 : 0;
+        const int l = u ? l1c : l0;
+        const int pl = pp - (u ? wpx0 : 0), ww = tc.ww[l];
+        const int dy = (int)udiv(pl, ww, tc.m_ww[l]);
+        const int gpix = tc.S0[l] + (tc.wy0[l] + dy) * tc.W[l] + tc.wx0[l] + pl - dy * ww;      // pixel of this group in the whole map
+        {
+          const float send1 = odd ? acc.x : acc.y, send2 = odd ? acc.z : acc.w;
+          const float got1 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send1), 0x128, 0xF, 0xF, true));   // row_ror:8 = lane ^ 8
+          const float got2 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send2), 0x128, 0xF, 0xF, true));
+          const int opx = __builtin_amdgcn_mov_dpp(valid ? gpix : -1, 0x128, 0xF, 0xF, true);
+          const int pixA = odd ? opx : (valid ? gpix : -1), pixB = odd ? (valid ? gpix : -1) : opx;
+          const int jj = j + (odd ? G : 0);
+          if (pixA >= 0) {
+            float* g = gvb + (long long)pixA * MD + jj;
+            atomicAdd(g, odd ? got1 : acc.x);
+            atomicAdd(g + 2 * G, odd ? got2 : acc.z);
+          }
+          if (pixB >= 0) {
+            float* g = gvb + (long long)pixB * MD + jj;
+            atomicAdd(g, odd ? acc.y : got1);
+            atomicAdd(g + 2 * G, odd ? acc.w : got2);
+          }
+        }
+        if (valid && j == 0) cnt[pp] = 0;        // ready for the next pass
+      }
+      lds_barrier();
+    }
+  }
+}
+
 inline size_t gather_lds(const ColGeom& g, int D, int P) {
   return (size_t)g.wmax * D * sizeof(float) + (size_t)g.tmax * P * (sizeof(float4) + sizeof(int)) + (size_t)g.tmax * sizeof(int);
 }
 
 inline size_t scatter_lds(const ColGeom& g, int D, int P) {
   return (size_t)g.tmax * D * sizeof(float) + (size_t)g.tmax * P * 4 * sizeof(Item) + (size_t)g.tmax * sizeof(int);
+}
+
+inline size_t scatter2_lds(const ColGeom& g, int D, int P) {
+  return (size_t)g.tmax * D * sizeof(float) + (size_t)g.tmax * P * 8 * sizeof(Item) + (size_t)g.tmax * sizeof(int);
+}
+
+// the level-pair kernel: G = 8 only, 768 threads, every pair of consecutive windows fits the 768 bins, LDS for two workgroups per CU
+inline bool scatter2_ok(const ColGeom& g, int D, int P) {
+  if (D != 32 || g.L > kLM || P < 1 || g.tmax * P > 768 || g.tmax * 8 > 2 * 768) return false;
+  if (scatter2_lds(g, D, P) > 70 * 1024) return false;
+  for (int l = 0; l < g.L; l += 2) {
+    int px = 0;
+    for (int u = l; u < std::min(l + 2, g.L); ++u) {
+      const int rmax = (g.H[u] + g.nty - 1) / g.nty, cmax = (g.W[u] + g.ntx - 1) / g.ntx;
+      px += std::min(g.H[u], std::max(rmax, 1) + kMarginLo + kMarginHi) * std::min(g.W[u], std::max(cmax, 1) + kMarginLo + kMarginHi);
+    }
+    if (px > 768) return false;
+  }
+  return true;
 }
 
 inline bool gather_ok(const ColGeom& g, int D, int P) {
@@ -604,6 +845,16 @@ int fwd_col(const float* value, const float* loc, const float* attn, int N, int 
 
 int bwd_scatter_col(const float* loc, const float* attn, const float* gout, int N, int S, int M, int D, int P, const ColGeom& g,
                     float* gvalue, hipStream_t st) {
+  {
+    static const int lp = [] { const char* e = std::getenv("OCPG_MSDA_COL_LP"); return e ? std::atoi(e) : 2; }();     // A/B: levels per pass
+    if (lp == 2 && scatter2_ok(g, D, P)) {
+      const size_t lds2 = scatter2_lds(g, D, P);
+      if (lds2 > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter_col2<8, 768>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+      k_scatter_col2<8, 768><<<(unsigned)((long long)N * g.ntiles * M), 768, lds2, st>>>(loc, attn, gout, S, M, P, g, gvalue);
+      return 1;
+    }
+  }
   const int nt = scatter_threads(g, D, P);
   if (!nt) return 0;
   const size_t lds = scatter_lds(g, D, P);
