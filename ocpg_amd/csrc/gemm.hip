@@ -225,6 +225,20 @@ __global__ void k_cmp(const void* c, const void* ref, int dt, long long n, unsig
   }
 }
 
+// second pass: number of elements with |c - ref| > rtol * |ref| + atol_frac * max|ref| (max|ref| = out[1] of the first pass, read on
+// the device: no host round trip between the passes) -> out[2].  The global bound alone (max|diff| against max|ref|) lets
+// small-magnitude elements be arbitrarily wrong in relative terms.
+__global__ void k_cmp_count(const void* c, const void* ref, int dt, long long n, float rtol, float atol_frac, unsigned* out) {
+  const float atol = atol_frac * __uint_as_float(out[1]);
+  unsigned bad = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float a = cmp_ld(c, dt, i), b = cmp_ld(ref, dt, i);
+    bad += !(fabsf(a - b) <= rtol * fabsf(b) + atol);
+  }
+  for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o, 64);
+  if ((threadIdx.x & 63) == 0 && bad) atomicAdd(out + 2, bad);
+}
+
 // First use of a plan whose call is repeatable (it does not accumulate into its own output): run every candidate of the heuristic's
 // ranked list on the caller's operands and keep the fastest ONE WHOSE RESULT AGREES with the default's (candidate 0: hipBLASLt's own
 // single choice, what at::mm would run) to the rounding of the output type.  Only bf16 / fp16 plans carry more than the default.  hipBLASLt's first choice is a
@@ -240,7 +254,7 @@ template <typename Launch> void tune(State& s, Plan& p, hipStream_t st, const vo
   const long long n = span;                   // the WHOLE output is compared: a candidate that is wrong only in its edge tiles was seen
   const size_t esize = dt == 0 ? 4 : 2;
   bool ready = s.ev0 || (hipEventCreate(&s.ev0) == hipSuccess && hipEventCreate(&s.ev1) == hipSuccess &&
-                         hipMalloc(reinterpret_cast<void**>(&s.cmp_out), 8) == hipSuccess);
+                         hipMalloc(reinterpret_cast<void**>(&s.cmp_out), 16) == hipSuccess);
   if (ready && s.cmp_bytes < (size_t)n * esize) {
     if (s.cmp_ref) (void)hipFree(s.cmp_ref);
     s.cmp_ref = nullptr;
@@ -262,8 +276,10 @@ template <typename Launch> void tune(State& s, Plan& p, hipStream_t st, const vo
       if (hipMemcpyAsync(s.cmp_ref, C, (size_t)n * esize, hipMemcpyDeviceToDevice, st) != hipSuccess) break;
       ref = i;
     } else {
-      (void)hipMemsetAsync(s.cmp_out, 0, 8, st);
+      (void)hipMemsetAsync(s.cmp_out, 0, 16, st);
       hipLaunchKernelGGL(k_cmp, dim3(256), dim3(256), 0, st, C, (const void*)s.cmp_ref, dt, n, s.cmp_out);
+      // per element: a few roundings of the output type relative to the element itself, plus a floor of tol / 4 of the largest
+      hipLaunchKernelGGL(k_cmp_count, dim3(256), dim3(256), 0, st, C, (const void*)s.cmp_ref, dt, n, 4.f * tol, 0.25f * tol, s.cmp_out);
     }
     (void)hipEventRecord(s.ev0, st);
     bool ok = true;
@@ -272,12 +288,12 @@ template <typename Launch> void tune(State& s, Plan& p, hipStream_t st, const vo
     float ms = 0.f;
     if (hipEventSynchronize(s.ev1) != hipSuccess || hipEventElapsedTime(&ms, s.ev0, s.ev1) != hipSuccess || !ok) continue;
     if (i != ref) {
-      unsigned bits[2] = {0x7f800000u, 0u};
-      if (hipMemcpy(bits, s.cmp_out, 8, hipMemcpyDeviceToHost) != hipSuccess) continue;
+      unsigned bits[3] = {0x7f800000u, 0u, 1u};
+      if (hipMemcpy(bits, s.cmp_out, 12, hipMemcpyDeviceToHost) != hipSuccess) continue;
       float diff, mag;
       memcpy(&diff, &bits[0], 4);
       memcpy(&mag, &bits[1], 4);
-      if (!(diff <= tol * mag + 1e-30f)) { s.tuned_rejected += 1; continue; }
+      if (!(diff <= tol * mag + 1e-30f) || bits[2] != 0u) { s.tuned_rejected += 1; continue; }
     }
     if (best < 0 || ms < best_ms) { best = i; best_ms = ms; }
   }

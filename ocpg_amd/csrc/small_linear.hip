@@ -35,7 +35,7 @@ __device__ __forceinline__ short ld_el(const void* p, int is_f32, long long ld, 
 // 16 consecutive elements of row `row` starting at column `col` (fp32 or bf16 storage) as bf16 bits, zeros outside the matrix;
 // 16-byte loads when the run is inside and aligned
 __device__ __forceinline__ void ld16_raw(short (&v)[16], const void* p, int is_f32, long long ld, int row, int col, int rows, int cols) {
-  if (row < rows && col + 16 <= cols && ((ld | col) & 7) == 0) {
+  if (row < rows && col + 16 <= cols && ((ld | col) & 7) == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {     // (a view with a storage offset may be unaligned)
     if (is_f32) {
       const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + row * ld + col);
 #pragma unroll
@@ -162,20 +162,26 @@ __global__ __launch_bounds__(NT) void sl_bwd(const void* __restrict__ gy, int gy
     const int t = blockIdx.x - n_dx;
     const int m0 = (t / ntn) * T, n0 = (t % ntn) * T;                   // m = co, n = ci
     const bool do_bias = gb && (t % ntn) == 0;
-    float bsum = 0.f;
     for (int k0 = 0; k0 < R; k0 += T) {
       stage_transposed(As, gy, gy_f32, Cout, k0, m0, R, Cout, ymask);   // A[m = co][k = r] = gy[r][co]
       stage_transposed(Bs, x, x_f32, Cin, k0, n0, R, Cin);              // B[n = ci][k = r] = x[r][ci]
       __syncthreads();
       acc = tile_mma(As, Bs, acc);
-      if (do_bias && threadIdx.x < T) {
-#pragma unroll 8
-        for (int k = 0; k < T; ++k) bsum += b2f(As[threadIdx.x * LROW + k]);
-      }
       __syncthreads();
     }
     store_tile(gw, 0, Cin, m0, n0, Cout, Cin, acc, nullptr);
-    if (do_bias && threadIdx.x < T && m0 + (int)threadIdx.x < Cout) gb[m0 + threadIdx.x] = f2b(bsum);
+    if (do_bias && threadIdx.x < T && m0 + (int)threadIdx.x < Cout) {
+      // bias gradient = column sum of gy in fp32 from the ORIGINAL values (ATen reduces the fp32 gradient before the cast; summing
+      // the bf16-rounded staged tile lost precision for heads with many rows -- ADVICE r2); 64 lanes read 64 consecutive columns
+      const int co = m0 + threadIdx.x;
+      float bsum = 0.f;
+      for (int r = 0; r < R; ++r) {
+        const long long i = (long long)r * Cout + co;
+        const float g = gy_f32 ? reinterpret_cast<const float*>(gy)[i] : b2f(reinterpret_cast<const short*>(gy)[i]);
+        bsum += (!ymask || b2f(ymask[i]) > 0.f) ? g : 0.f;
+      }
+      gb[co] = f2b(bsum);
+    }
   }
 }
 

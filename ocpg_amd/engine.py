@@ -151,13 +151,17 @@ def evaluate_referred_masks(model, data_loader, postprocessor, device, amp_dtype
         for p, t in zip(postprocessor(outputs, orig, size), targets):
             best = metrics.select_best_query(p["scores"][None], p["masks"][None, :, 0])      # [1, H0, W0]
             state = metrics.accumulate(state, best, t["gt_mask"][None].bool())
-    if state is None:
-        return {}
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        ious = torch.cat(state[0])
-        gathered = [None] * dist.get_world_size()
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    if world > 1:
+        # every rank enters the collectives, also one whose loader was empty (the reference always reaches its all_gather /
+        # barrier, engine.py:170-176; a rank-local early return would leave the others waiting)
+        dev = torch.device(device)
+        ious = torch.cat(state[0]) if state is not None else torch.zeros(0, device=dev)
+        gathered = [None] * world
         dist.all_gather_object(gathered, ious.cpu())
-        sums = torch.stack([state[1], state[2]]).to(torch.float64)
+        sums = (torch.stack([state[1], state[2]]) if state is not None else torch.zeros(2, device=dev)).to(torch.float64)
         dist.all_reduce(sums)
-        state = ([g.to(ious.device) for g in gathered], sums[0].float(), sums[1].float())
+        state = ([g.to(dev) for g in gathered], sums[0].float(), sums[1].float())
+    if state is None or sum(g.numel() for g in state[0]) == 0:
+        return {}
     return metrics.summarize(state)

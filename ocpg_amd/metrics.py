@@ -45,6 +45,6 @@ def accumulate(state, pred: Tensor, gt: Tensor):
 def summarize(state, thresholds: Sequence[float] = THRESHOLDS) -> Dict[str, float]:
     ious = torch.cat(state[0])
     out = {"P@%s" % k: float((ious > k).float().mean()) for k in thresholds}
-    out["overall_iou"] = float(state[1] / state[2])
+    out["overall_iou"] = float(state[1] / state[2]) if float(state[2]) > 0 else 0.0      # all masks empty: no union
     out["mean_iou"] = float(ious.mean())
     return out
