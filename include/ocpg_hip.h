@@ -258,6 +258,11 @@ int ocpg_multi_cast(const long long* srcs, const long long* dsts, const long lon
 int ocpg_multi_cast_sum(const long long* srcs, const long long* dsts, const long long* numels, const long long* chunk_prefix,
                         const long long* splits, const long long* strides, int n, long long total_chunks, int src_dtype, int dst_dtype,
                         void* stream);
+/* Partial column sums of x [R, C] (dtype 0 fp32 / 1 bf16 / 2 fp16) -> part [ocpg_colsum_blocks(R), C] fp32, fully written: the
+ * bias gradient `grad_output.sum(0)` of nn.Linear / a 1x1 nn.Conv2d over many rows (models/deformable_transformer.py:236-257 FFNs,
+ * models/modules.py:12-16 LFM convolutions) as ONE launch; ocpg_multi_cast_sum finishes the sum over the blocks. */
+long long ocpg_colsum_blocks(long long R);
+int ocpg_colsum_partials(const void* x, long long R, int C, int dtype, float* part, void* stream);
 
 /* Classification (sigmoid focal, alpha < 0 disables the alpha weighting) + L1 + GIoU losses of the matched queries, all layers
  * per launch -- replaces SetCriterion.loss_labels / loss_boxes (models/criterion.py:46-107; sigmoid_focal_loss

@@ -65,6 +65,8 @@ SIGNATURES = {
     "ocpg_bias_relu_dropout_bwd_slots": [ctypes.c_longlong, _int, _int],
     "ocpg_multi_cast": [_vp] * 4 + [_int, ctypes.c_longlong, _int, _int, _vp],
     "ocpg_multi_cast_sum": [_vp] * 6 + [_int, ctypes.c_longlong, _int, _int, _vp],
+    "ocpg_colsum_blocks": [ctypes.c_longlong],
+    "ocpg_colsum_partials": [_vp, ctypes.c_longlong, _int, _int, _vp, _vp],
     "ocpg_det_loss_fwd_f32": [_vp] * 7 + [ctypes.c_float] + [_int] * 5 + [_vp] * 3,
     "ocpg_det_loss_bwd_f32": [_vp] * 8 + [ctypes.c_float] + [_int] * 5 + [_vp] * 3,
     "ocpg_spectral_gate_fwd": [_vp] * 3 + [_int] * 3 + [_vp, _vp],
@@ -88,7 +90,7 @@ SIGNATURES = {
 
 # ---- optional live kernel timing (bench.py): HIP events on the launch stream around every library call ----------
 _TIMING = {"on": False, "events": []}
-_UNTIMED = ("ocpg_gemm_plans", "ocpg_gemm_tuned", "ocpg_gemm_tune_rejected", "ocpg_bias_relu_dropout_bwd_slots", "ocpg_dropout_add_ln_bwd_slots", "ocpg_groupnorm_cl_work")
+_UNTIMED = ("ocpg_colsum_blocks", "ocpg_gemm_plans", "ocpg_gemm_tuned", "ocpg_gemm_tune_rejected", "ocpg_bias_relu_dropout_bwd_slots", "ocpg_dropout_add_ln_bwd_slots", "ocpg_groupnorm_cl_work")
 
 
 def enable_kernel_timing(on=True):
@@ -180,6 +182,7 @@ def lib():
         L.ocpg_bias_relu_dropout_bwd_slots.restype = ctypes.c_longlong
         L.ocpg_dropout_add_ln_bwd_slots.restype = ctypes.c_longlong
         L.ocpg_groupnorm_cl_work.restype = ctypes.c_longlong
+        L.ocpg_colsum_blocks.restype = ctypes.c_longlong
         _lib = _Lib(L)
     return _lib
 

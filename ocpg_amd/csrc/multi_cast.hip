@@ -42,9 +42,20 @@ __global__ __launch_bounds__(256) void multi_cast_sum(const long long* __restric
   }
   const S* s = reinterpret_cast<const S*>(srcs[lo]);
   D* d = reinterpret_cast<D*>(dsts[lo]);
-  const long long count = numels[lo], ns = splits[lo], stride = strides[lo];
+  const long long count = numels[lo], stride = strides[lo];
+  long long ns = splits[lo];
   const long long base = (blk - chunk_prefix[lo]) * CHUNK + (long long)threadIdx.x * 8;
   if (base >= count) return;
+  if (ns >> 40) {             // bit 40: THIS tensor's slices are fp32 whatever S is (bias-gradient partials of ocpg_colsum_partials)
+    ns &= (1LL << 40) - 1;
+    const float* sf = reinterpret_cast<const float*>(srcs[lo]);
+    for (long long i = base; i < base + 8 && i < count; ++i) {
+      float a = 0.f;
+      for (long long k = 0; k < ns; ++k) a += sf[k * stride + i];
+      d[i] = from_f<D>(a);
+    }
+    return;
+  }
   const bool wide = base + 8 <= count && ((reinterpret_cast<uintptr_t>(s + base) | reinterpret_cast<uintptr_t>(d + base)) & 15) == 0 &&
                     (ns == 1 || (stride * (long long)sizeof(S)) % 16 == 0);
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -114,6 +125,46 @@ extern "C" int ocpg_multi_cast(const long long* srcs, const long long* dsts, con
   else if (src_dtype == 1 && dst_dtype == 0) MC(__hip_bfloat16, float);
   else if (src_dtype == 2 && dst_dtype == 0) MC(__half, float);
   else return -1010;
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// Partial column sums of a row-major [R, C] matrix (bf16 / fp16 / fp32): workgroup s sums its block of rows for every column ->
+// part [S, C] fp32, every element written.  The bias gradient of a Linear / 1x1 conv over many rows is the column sum of the output
+// gradient; ATen's `sum(0)` is two launches (semaphore fill + reduction) per layer -- here ONE launch leaves S partial rows and the
+// fused gradient cast (multi_cast_sum above) finishes the sum while it casts.
+template <typename S>
+__global__ __launch_bounds__(256) void colsum_partials(const S* __restrict__ x, long long R, int C, long long rows_per_block,
+                                                       float* __restrict__ part) {
+  const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    long long r = r0;
+    for (; r + 4 <= r1; r += 4) {
+      a0 += to_f<S>(x[r * C + c]); a1 += to_f<S>(x[(r + 1) * C + c]); a2 += to_f<S>(x[(r + 2) * C + c]); a3 += to_f<S>(x[(r + 3) * C + c]);
+    }
+    for (; r < r1; ++r) a0 += to_f<S>(x[r * C + c]);
+    part[(long long)blockIdx.x * C + c] = (a0 + a1) + (a2 + a3);
+  }
+}
+
+extern "C" long long ocpg_colsum_blocks(long long R) {
+  if (R <= 0) return 0;
+  const long long want = (R + 127) / 128;
+  return want < 512 ? want : 512;
+}
+
+extern "C" int ocpg_colsum_partials(const void* x, long long R, int C, int dtype, float* part, void* stream) {
+  if (R < 0 || C <= 0) return -1002;
+  if (R == 0) return 0;
+  if (!x) return -1001;
+  if (!part) return -1005;
+  const long long blocks = ocpg_colsum_blocks(R), rpb = (R + blocks - 1) / blocks;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 0) colsum_partials<float><<<(unsigned)blocks, 256, 0, st>>>((const float*)x, R, C, rpb, part);
+  else if (dtype == 1) colsum_partials<__hip_bfloat16><<<(unsigned)blocks, 256, 0, st>>>((const __hip_bfloat16*)x, R, C, rpb, part);
+  else if (dtype == 2) colsum_partials<__half><<<(unsigned)blocks, 256, 0, st>>>((const __half*)x, R, C, rpb, part);
+  else return -1004;
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }

@@ -83,13 +83,48 @@ DEFER_SUM = os.environ.get("OCPG_DEFER_WGRAD_SUM", "1") != "0"     # A/B switch
 _PARTIALS = {}          # data_ptr of slice 0 -> (splits, stride in elements, numel of a slice)
 
 
-def defer_sum(part):
+def defer_sum(part, as_dtype=None):
     """part [S, ...] partial products of ONE weight gradient -> slice 0, with the promise that FusedCast.backward adds the other S-1
     slices while it casts (csrc/multi_cast.hip: multi_cast_sum).  Only for the working copy of a parameter that is used ONCE per
     forward: the autograd engine must hand this very tensor to FusedCast.backward (it would sum two uses into a new tensor; an
-    entry that nobody consumed raises there)."""
-    _PARTIALS[part.data_ptr()] = (part.shape[0], part.stride(0), part[0].numel())
-    return part[0]
+    entry that nobody consumed raises at the next forward).  as_dtype: the partials are fp32 but the gradient autograd expects has
+    this (low-precision) dtype: slice 0 is handed over as a low-precision VIEW of the same memory (never read as such)."""
+    s0 = part[0]
+    if as_dtype is not None and as_dtype != part.dtype:
+        assert part.dtype == torch.float32 and part.is_contiguous()
+        _PARTIALS[part.data_ptr()] = (part.shape[0] | (1 << 40), part.stride(0), s0.numel())
+        return part.view(as_dtype)[0, :s0.numel()].view(s0.shape)       # same address, the dtype the engine checks
+    _PARTIALS[part.data_ptr()] = (part.shape[0], part.stride(0), s0.numel())
+    return s0
+
+
+def mark_single_use(*modules_or_params):
+    """Declare that these parameters are used ONCE per forward, so the sums over the row-split partials of their gradients (and the
+    column sums behind bias gradients) may be left to the fused gradient cast (defer_sum).  NOT for shared modules (a module
+    applied to several levels: the engine sums the uses into a new tensor and the partials would be lost -- caught at the next
+    forward, loudly)."""
+    for m in modules_or_params:
+        for p_ in (m.parameters() if isinstance(m, nn.Module) else [m]):
+            p_._ocpg_single_use = True
+
+
+def deferrable(w):
+    """True for a FusedCast working copy of a parameter marked single-use (tagged by `scope`)."""
+    return DEFER_SUM and MULTI_CAST and w is not None and getattr(w, "_ocpg_defer", False)
+
+
+def colsum(gy2, like):
+    """gy2 [R, C].sum(0) as the gradient of the bias working copy `like`; deferred (one launch of partials now, the sum inside the
+    fused gradient cast) when `like` is deferrable and gy2 is a low-precision GPU matrix."""
+    if deferrable(like) and gy2.is_cuda and gy2.dtype in (torch.bfloat16, torch.float16) and gy2.is_contiguous() and like.dtype == gy2.dtype:
+        from .._lib import check, lib
+        r, c = gy2.shape
+        nb = int(lib().ocpg_colsum_blocks(r))
+        part = torch.empty((nb, c), dtype=torch.float32, device=gy2.device)
+        check(lib().ocpg_colsum_partials(gy2.data_ptr(), r, c, _DT[gy2.dtype], part.data_ptr(), torch.cuda.current_stream().cuda_stream),
+              "ocpg_colsum_partials")
+        return defer_sum(part, gy2.dtype)
+    return gy2.sum(0)
 
 
 def is_cast_copy(w):
@@ -291,8 +326,9 @@ def _mm(a, b, trans_b=False, bias=None):
     return mm(a, b, trans_b, bias)
 
 
-def weight_grad(gy2, x2):
-    """gy2 [M, Co], x2 [M, Ci] (row-major, M = pixels or tokens, large) -> gy2^T x2 [Co, Ci].
+def weight_grad(gy2, x2, defer=False):
+    """gy2 [M, Co], x2 [M, Ci] (row-major, M = pixels or tokens, large) -> gy2^T x2 [Co, Ci].  defer: leave the sum over the row
+    chunks to the fused gradient cast (defer_sum; the caller checked `deferrable(weight copy)`).
 
     As ONE GEMM this has a tiny output and a huge reduction dimension: hipBLASLt runs it on a handful of workgroups
     (measured on MI355X, bf16: M=38400, 512x128 -> 138 us; M=153600, 256x64 -> 360 us; fp32 M=51000, 256x256 -> 201 us).
@@ -302,7 +338,7 @@ def weight_grad(gy2, x2):
     s = _split_rows(m) if SPLIT_K else 1
     if gy2.is_cuda:
         from .ops.functions.gemm_func import mm_tn
-        return mm_tn(gy2, x2, s)
+        return mm_tn(gy2, x2, s, defer and gy2.dtype in (torch.bfloat16, torch.float16))
     if s == 1:
         return torch.mm(gy2.t(), x2)
     return torch.bmm(gy2.view(s, m // s, -1).transpose(1, 2), x2.view(s, m // s, -1)).sum(0)
@@ -322,6 +358,7 @@ class Conv1x1AsGemm(torch.autograd.Function):
         y2 = _mm(x2, w2, True, bias)
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
+        ctx.defer_w, ctx.defer_b = deferrable(w), bias if deferrable(bias) else None
         return y2.view(n, h, wd, w.shape[0]).permute(0, 3, 1, 2)
 
     @staticmethod
@@ -334,9 +371,9 @@ class Conv1x1AsGemm(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = _mm(gy2, w.reshape(co, c)).view(n, h, wd, c).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
-            gw = weight_grad(gy2, x.permute(0, 2, 3, 1).reshape(n * h * wd, c)).view(w.shape)
+            gw = weight_grad(gy2, x.permute(0, 2, 3, 1).reshape(n * h * wd, c), ctx.defer_w).view(w.shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = gy2.sum(0)
+            gb = colsum(gy2, ctx.defer_b)
         return gx, gw, gb
 
 
@@ -347,6 +384,7 @@ class TokenLinearFunction(torch.autograd.Function):
     def forward(ctx, x2, w, bias):
         ctx.save_for_backward(x2, w)
         ctx.has_bias = bias is not None
+        ctx.defer_w, ctx.defer_b = deferrable(w), bias if deferrable(bias) else None
         return _mm(x2, w, True, bias)
 
     @staticmethod
@@ -354,8 +392,8 @@ class TokenLinearFunction(torch.autograd.Function):
         x2, w = ctx.saved_tensors
         gy = gy.contiguous()
         gx = _mm(gy, w) if ctx.needs_input_grad[0] else None
-        gw = weight_grad(gy, x2) if ctx.needs_input_grad[1] else None
-        gb = gy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        gw = weight_grad(gy, x2, ctx.defer_w) if ctx.needs_input_grad[1] else None
+        gb = colsum(gy, ctx.defer_b) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return gx, gw, gb
 
 
@@ -546,6 +584,10 @@ def scope(module):
             if isinstance(plan, _NoPlan):
                 plan = None
         outs = FusedCast.apply(low, plan, *params)
+        if plan is not None:
+            for p, o in zip(params, outs):
+                if getattr(p, "_ocpg_single_use", False) and p.requires_grad:
+                    o._ocpg_defer = True            # layers may leave partial sums of this gradient to FusedCast.backward
         _ACTIVE.update({id(p): o for p, o in zip(params, outs)})
     try:
         yield

@@ -68,9 +68,11 @@ class DeformableTransformerEncoderLayer(nn.Module):
         self.dropout1 = nn.Dropout(dropout)
         self.norm1 = nn.LayerNorm(d_model)
         self.linear1 = amp_cache.Linear(d_model, d_ffn)
+        amp_cache.mark_single_use(self.linear1)
         self.activation = _activation(activation)
         self.dropout2 = nn.Dropout(dropout)
         self.linear2 = amp_cache.Linear(d_ffn, d_model)
+        amp_cache.mark_single_use(self.linear2)
         self.dropout3 = nn.Dropout(dropout)
         self.norm2 = nn.LayerNorm(d_model)
 
@@ -124,9 +126,11 @@ class DeformableTransformerDecoderLayer(nn.Module):
         self.dropout2 = nn.Dropout(dropout)
         self.norm2 = nn.LayerNorm(d_model)
         self.linear1 = amp_cache.Linear(d_model, d_ffn)
+        amp_cache.mark_single_use(self.linear1)
         self.activation = _activation(activation)
         self.dropout3 = nn.Dropout(dropout)
         self.linear2 = amp_cache.Linear(d_ffn, d_model)
+        amp_cache.mark_single_use(self.linear2)
         self.dropout4 = nn.Dropout(dropout)
         self.norm3 = nn.LayerNorm(d_model)
 

@@ -23,6 +23,7 @@ class LFMResizeAdaptive(nn.Module):
         super().__init__()
         self.conv1 = amp_cache.Conv2d(2 * num_channels, 2 * num_channels, kernel_size=1)
         self.conv2 = amp_cache.Conv2d(2 * num_channels, 2 * num_channels, kernel_size=1)
+        amp_cache.mark_single_use(self.conv1, self.conv2)       # applied once per forward: their gradient sums ride in the fused cast
         self.sigma = sigma
         self.laplace = amp_cache.Conv2d(num_channels, num_channels, kernel_size=3, padding=0)
         self.pool = nn.AdaptiveAvgPool2d(1)

@@ -130,6 +130,7 @@ class OCPG(nn.Module):
         proj, fft, fft_post = [], [], []
         for cin in chans:
             proj.append(nn.Sequential(amp_cache.Conv2d(cin, hidden_dim, kernel_size=1), GroupNorm(32, hidden_dim)))
+            amp_cache.mark_single_use(proj[-1][0])
         cin = chans[-1]
         for _ in range(num_feature_levels - len(chans)):
             proj.append(nn.Sequential(amp_cache.Conv2d(cin, hidden_dim, kernel_size=3, stride=2, padding=1), GroupNorm(32, hidden_dim)))

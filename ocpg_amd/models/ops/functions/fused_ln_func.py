@@ -124,6 +124,8 @@ class LinearBiasReluDropout(Function):
               "ocpg_bias_relu_dropout_fwd")
         ctx.save_for_backward(x2, w, h)
         ctx.meta = (float(p), splits)
+        from ...amp_cache import deferrable
+        ctx.defer_w, ctx.defer_b = deferrable(w), deferrable(b) and b.dtype == h.dtype
         return h
 
     @staticmethod
@@ -139,10 +141,12 @@ class LinearBiasReluDropout(Function):
         part = torch.empty((slots, c), dtype=torch.float32, device=h.device)
         check(lib().ocpg_bias_relu_dropout_bwd(gh.data_ptr(), h.data_ptr(), r, c, p, _DT[h.dtype], ga.data_ptr(), part.data_ptr(), _st()),
               "ocpg_bias_relu_dropout_bwd")
-        dbias = part.sum(0)
+        from ...amp_cache import defer_sum
+        # the per-slot partial column sums: summed inside the fused gradient cast when the bias copy allows it (one launch less + no cast)
+        dbias = defer_sum(part, h.dtype) if (ctx.defer_b and ctx.needs_input_grad[2] and h.dtype != torch.float32) else part.sum(0).to(h.dtype)
         gx = mm(ga, w) if ctx.needs_input_grad[0] else None
-        gw = weight_grad(ga, x2) if ctx.needs_input_grad[1] else None
-        return gx, gw, dbias.to(h.dtype) if ctx.needs_input_grad[2] else None, None, None, None
+        gw = weight_grad(ga, x2, ctx.defer_w) if ctx.needs_input_grad[1] else None
+        return gx, gw, dbias if ctx.needs_input_grad[2] else None, None, None, None
 
 
 def supported(x, res, c):

@@ -27,13 +27,14 @@ def mm(a, b, trans_b=False, bias=None):
     return torch.mm(a, bb) if bias is None else torch.addmm(bias, a, bb)
 
 
-def mm_tn(a, b, splits=1):
-    """a [R,M]^T @ b [R,N] -> [M,N] (weight-gradient form), optionally reduced over `splits` row chunks (batched GEMM + sum)."""
+def mm_tn(a, b, splits=1, defer=False):
+    """a [R,M]^T @ b [R,N] -> [M,N] (weight-gradient form), optionally reduced over `splits` row chunks (batched GEMM + sum; with
+    `defer` the sum is left to the fused gradient cast: amp_cache.defer_sum)."""
     if PLANNED and _plain(a) and _plain(b) and a.dtype == b.dtype:
         if splits == 1:
             return gemm(a, b, True, False)
         if a.is_contiguous() and b.is_contiguous():
-            return gemm_tn_split(a, b, splits)
+            return gemm_tn_split(a, b, splits, defer)
     if splits == 1:
         return torch.mm(a.t(), b)
     r = a.shape[0]
@@ -61,7 +62,7 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None):
     return out
 
 
-def gemm_tn_split(a, b, splits):
+def gemm_tn_split(a, b, splits, defer=False):
     """a [R, M], b [R, N] (row-major, R = splits * r) -> a^T b [M, N], reduced over `splits` row chunks as one strided-batched
     GEMM + one sum (see amp_cache.weight_grad for why)."""
     r = a.shape[0] // splits
@@ -72,4 +73,7 @@ def gemm_tn_split(a, b, splits):
                          1.0, 0.0, torch.cuda.current_stream().cuda_stream)
     if rc:
         check(rc, "ocpg_gemm")
+    if defer:
+        from ...amp_cache import defer_sum
+        return defer_sum(part)
     return part.sum(0)

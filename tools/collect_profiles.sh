@@ -8,6 +8,7 @@ timeout -k 10 500 python bench.py > $O/bench_line_graph_2clips.json 2> $O/bench_
 echo "[1] default bench done"
 timeout -k 10 300 python bench.py --eager --no-cpu-baseline > $O/bench_line_eager_2clips.json 2> $O/bench_eager.err || exit 1
 timeout -k 10 300 python bench.py --clips-per-gpu 1 --no-cpu-baseline > $O/bench_line_graph_1clip.json 2> $O/bench_1clip.err || exit 1
+OCPG_GRAPH_SEGMENTS=3 timeout -k 10 300 python bench.py --no-cpu-baseline --no-kernel-timing --no-b1 > $O/bench_line_graph_3segments.json 2> $O/bench_3seg.err || exit 1
 echo "[2] eager / 1-clip lines done"
 rm -rf /tmp/prof_main
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_main -- python bench.py --steps 6 --warmup 4 --no-cpu-baseline --no-kernel-timing --no-b1 > $O/bench_under_rocprof.log 2>&1 || exit 1
@@ -22,10 +23,12 @@ timeout -k 10 400 python bench.py --backbone video_swin_t_p4w7 --steps 10 --warm
 rm -rf /tmp/prof_swint
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_swint -- python bench.py --backbone video_swin_t_p4w7 --steps 5 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-b1 > $O/swint_under_rocprof.log 2>&1 || exit 1
 cp $(find /tmp/prof_swint -name "*kernel_stats.csv" | head -1) $O/swint_rocprofv3_kernel_stats.csv
+python tools/summarize_trace.py $(find /tmp/prof_swint -name "*kernel_trace.csv" | head -1) $O/swint_steady_state_per_step.csv 2 k_scatter_col 4 > $O/swint_steady_summary.txt; cat $O/swint_steady_summary.txt
 echo "[5] Swin-T done"
 [ -n "$SKIP_SWINB" ] && exit 0
 timeout -k 10 500 python bench.py --backbone video_swin_b_p4w7 --dtype fp16 --text roberta --frames 8 --height 480 --width 854 --clips-per-gpu 1 --steps 6 --warmup 3 --no-cpu-baseline > $O/bench_line_swinb_roberta_fp16.json 2> $O/bench_swinb.err || { tail -5 $O/bench_swinb.err; exit 1; }
 rm -rf /tmp/prof_swinb
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_swinb -- python bench.py --backbone video_swin_b_p4w7 --dtype fp16 --text roberta --frames 8 --height 480 --width 854 --clips-per-gpu 1 --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-b1 > $O/swinb_under_rocprof.log 2>&1 || exit 1
 cp $(find /tmp/prof_swinb -name "*kernel_stats.csv" | head -1) $O/swinb_roberta_fp16_rocprofv3_kernel_stats.csv
+python tools/summarize_trace.py $(find /tmp/prof_swinb -name "*kernel_trace.csv" | head -1) $O/swinb_steady_state_per_step.csv 2 k_scatter_col 4 > $O/swinb_steady_summary.txt; cat $O/swinb_steady_summary.txt
 echo "[6] Swin-B + RoBERTa fp16 done"
