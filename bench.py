@@ -82,6 +82,9 @@ def make_optimizer(model, args, fused=True):
         {"params": [p for n, p in named if has(n, args.lr_linear_proj_names)], "lr": args.lr * args.lr_linear_proj_mult},
     ]
     groups = [g for g in groups if g["params"]]
+    if fused and groups and groups[0]["params"][0].is_cuda and os.environ.get("OCPG_CLIP_ADAMW", "1") != "0":
+        from ocpg_amd.optim import ClipAdamW            # clip + AdamW as three HIP launches (csrc/adamw.hip); torch.optim.AdamW state layout
+        return ClipAdamW(groups, lr=args.lr, weight_decay=args.weight_decay)
     return torch.optim.AdamW(groups, lr=args.lr, weight_decay=args.weight_decay, fused=fused)
 
 
@@ -124,6 +127,9 @@ class EagerStep:
         self.optimizer.zero_grad(set_to_none=True)
         loss = forward_backward(self.ddp_model, self.criterion, self.make_samples(), self.text, self.targets, self.amp_dtype,
                                 scaler=self.scaler)
+        if self.scaler is None and hasattr(self.optimizer, "step_clip"):
+            self.grad_norm = self.optimizer.step_clip(self.args.clip_max_norm)     # norm + clip + AdamW: three launches
+            return loss
         if self.scaler is not None:
             self.scaler.unscale_(self.optimizer)
         if self.args.clip_max_norm > 0:
@@ -282,6 +288,9 @@ class GraphStep:
         if self.fence:
             torch.cuda.synchronize()
         self.criterion.iter_device += self.calls_per_fwd
+        if self.scaler is None and hasattr(self.optimizer, "step_clip"):
+            self.grad_norm = self.optimizer.step_clip(self.args.clip_max_norm)     # norm + clip + AdamW: three launches
+            return self.loss
         if self.scaler is not None:
             self.scaler.unscale_(self.optimizer)
         if self.args.clip_max_norm > 0:

@@ -264,6 +264,20 @@ int ocpg_multi_cast_sum(const long long* srcs, const long long* dsts, const long
 long long ocpg_colsum_blocks(long long R);
 int ocpg_colsum_partials(const void* x, long long R, int C, int dtype, float* part, void* stream);
 
+/* Gradient clipping + AdamW over MANY fp32 tensors (device tables of pointers / element counts / 2048-element chunk prefixes, as
+ * ocpg_multi_cast) -- replaces torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW.step of engine.py:100-106 / main.py:76-99:
+ *   ocpg_grad_norm_clip: partials [total_chunks] (scratch) -> norm_and_coef[0] = total 2-norm of all gradients,
+ *                        norm_and_coef[1] = min(1, max_norm / (norm + 1e-6)) (1 when max_norm <= 0); two launches;
+ *   ocpg_adamw_step:     p, exp_avg, exp_avg_sq updated in one launch; the gradient is multiplied by norm_and_coef[1] on the fly (NULL:
+ *                        no clipping); lr / weight_decay: per-tensor fp32 device arrays (the optimizer's groups); step >= 1 is the
+ *                        step count AFTER this update (bias corrections).  betas / eps are doubles: 1 - beta is formed in double, as
+ *                        torch's Python scalars are (1.f - 0.999f is 4.7e-5 off 0.001).  Arithmetic = torch's single-tensor AdamW. */
+int ocpg_grad_norm_clip(const long long* grads, const long long* numels, const long long* chunk_prefix, int n, long long total_chunks,
+                        float max_norm, float* partials, float* norm_and_coef, void* stream);
+int ocpg_adamw_step(const long long* params, const long long* grads, const long long* exp_avg, const long long* exp_avg_sq,
+                    const long long* numels, const long long* chunk_prefix, const float* lr, const float* weight_decay, int n,
+                    long long total_chunks, const float* norm_and_coef, double beta1, double beta2, double eps, long long step, void* stream);
+
 /* Classification (sigmoid focal, alpha < 0 disables the alpha weighting) + L1 + GIoU losses of the matched queries, all layers
  * per launch -- replaces SetCriterion.loss_labels / loss_boxes (models/criterion.py:46-107; sigmoid_focal_loss
  * models/segmentation.py:134-160; util/box_ops.py:45-85).  logits [Lr,B,T,Q,K], boxes [Lr,B,T,Q,4] (cxcywh), src [Lr,B] int64

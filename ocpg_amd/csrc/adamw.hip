@@ -1,0 +1,161 @@
+// Gradient clipping + AdamW for MANY parameter tensors in three launches ("fused multi-tensor AdamW + grad-clip
+// kernel").  Reference: engine.py:100-106 (`clip_grad_norm_(model.parameters(), max_norm)` then `optimizer.step()`) with main.py:76-99's
+// four-group torch.optim.AdamW.  torch runs this as ~10 foreach launches for the norm + one multiply of every gradient by the clip
+// coefficient (a full read + write of all gradients) + 12 multi-tensor AdamW launches; here:
+//   (1) sqnorm_partials : one partial sum of squares per 2048-element chunk of every gradient (device table of pointers, as multi_cast)
+//   (2) norm_finish     : one workgroup folds the partials -> out[0] = total 2-norm, out[1] = clip coefficient min(1, max_norm / (norm + 1e-6))
+//   (3) adamw_apply     : p, m, v updated in one pass; the gradient is scaled by the coefficient ON THE FLY (never rewritten);
+//                         per-tensor learning rate and weight decay (the optimizer's groups), bias corrections passed by value.
+// Arithmetic = torch's _single_tensor_adamw (decoupled weight decay first, then the moment updates, then
+// p -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps)).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ocpg_hip.h"
+
+namespace {
+
+constexpr int CHUNK = 2048;     // elements per workgroup: 256 lanes x 8
+
+__device__ __forceinline__ int find_tensor(const long long* __restrict__ chunk_prefix, int n, long long blk) {
+  int lo = 0, hi = n;                       // largest t with chunk_prefix[t] <= blk
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (chunk_prefix[mid] <= blk) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void sqnorm_partials(const long long* __restrict__ grads, const long long* __restrict__ numels,
+                                                       const long long* __restrict__ chunk_prefix, int n, float* __restrict__ part) {
+  const long long blk = blockIdx.x;
+  const int t = find_tensor(chunk_prefix, n, blk);
+  const float* g = reinterpret_cast<const float*>(grads[t]);
+  const long long count = numels[t];
+  const long long base = (blk - chunk_prefix[t]) * CHUNK + (long long)threadIdx.x * 8;
+  float s = 0.f;
+  if (base + 8 <= count && (reinterpret_cast<uintptr_t>(g + base) & 15) == 0) {
+    const float4 a = *reinterpret_cast<const float4*>(g + base), b = *reinterpret_cast<const float4*>(g + base + 4);
+    s = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+  } else {
+    for (long long i = base; i < base + 8 && i < count; ++i) s += g[i] * g[i];
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  __shared__ float ws[4];
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blk] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
+__global__ __launch_bounds__(1024) void norm_finish(const float* __restrict__ part, long long n, float max_norm, float* __restrict__ out) {
+  double s = 0.0;
+  for (long long i = threadIdx.x; i < n; i += 1024) s += (double)part[i];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  __shared__ double ws[16];
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < 16; ++i) t += ws[i];
+    const float norm = (float)sqrt(t);
+    out[0] = norm;
+    // torch.nn.utils.clip_grad_norm_: clip_coef = max_norm / (total_norm + 1e-6), clamped to 1 (a NaN norm stays NaN)
+    const float coef = max_norm / (norm + 1e-6f);
+    out[1] = max_norm > 0.f ? (coef < 1.f ? coef : (coef != coef ? coef : 1.f)) : 1.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void adamw_apply(const long long* __restrict__ params, const long long* __restrict__ grads,
+                                                   const long long* __restrict__ exp_avg, const long long* __restrict__ exp_avg_sq,
+                                                   const long long* __restrict__ numels, const long long* __restrict__ chunk_prefix,
+                                                   const float* __restrict__ lr, const float* __restrict__ wd, int n, const float* __restrict__ clip,
+                                                   float om_beta1, float beta2, float om_beta2, float eps, float bc1, float rsqrt_bc2) {
+  const long long blk = blockIdx.x;
+  const int t = find_tensor(chunk_prefix, n, blk);
+  float* p = reinterpret_cast<float*>(params[t]);
+  const float* g = reinterpret_cast<const float*>(grads[t]);
+  float* m = reinterpret_cast<float*>(exp_avg[t]);
+  float* v = reinterpret_cast<float*>(exp_avg_sq[t]);
+  const long long count = numels[t];
+  const float lr_t = lr[t], decay = 1.f - lr_t * wd[t], step_size = lr_t / bc1, coef = clip ? clip[1] : 1.f;
+  const long long base = (blk - chunk_prefix[t]) * CHUNK + (long long)threadIdx.x * 8;
+  if (base >= count) return;
+  const bool wide = base + 8 <= count && ((reinterpret_cast<uintptr_t>(p + base) | reinterpret_cast<uintptr_t>(g + base) |
+                                           reinterpret_cast<uintptr_t>(m + base) | reinterpret_cast<uintptr_t>(v + base)) & 15) == 0;
+  float pv[8], gv[8], mv[8], vv[8];
+  const int cnt = wide ? 8 : (int)((count - base) < 8 ? (count - base) : 8);
+  if (wide) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      *reinterpret_cast<float4*>(pv + 4 * h) = *reinterpret_cast<const float4*>(p + base + 4 * h);
+      *reinterpret_cast<float4*>(gv + 4 * h) = *reinterpret_cast<const float4*>(g + base + 4 * h);
+      *reinterpret_cast<float4*>(mv + 4 * h) = *reinterpret_cast<const float4*>(m + base + 4 * h);
+      *reinterpret_cast<float4*>(vv + 4 * h) = *reinterpret_cast<const float4*>(v + base + 4 * h);
+    }
+  } else {
+    for (int i = 0; i < cnt; ++i) { pv[i] = p[base + i]; gv[i] = g[base + i]; mv[i] = m[base + i]; vv[i] = v[base + i]; }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (i < cnt) {
+      const float gi = gv[i] * coef;
+      float pi = pv[i] * decay;
+      // (1 - beta) comes from the host in double precision, as torch's Python scalars do: 1.f - 0.999f is 4.7e-5 off 0.001
+      const float mi = mv[i] + (gi - mv[i]) * om_beta1;               // lerp form, as torch: exp_avg.lerp_(grad, 1 - beta1)
+      const float vi = vv[i] * beta2 + gi * gi * om_beta2;            // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+      const float denom = sqrtf(vi) * rsqrt_bc2 + eps;
+      pi -= step_size * (mi / denom);
+      pv[i] = pi; mv[i] = mi; vv[i] = vi;
+    }
+  }
+  if (wide) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      *reinterpret_cast<float4*>(p + base + 4 * h) = *reinterpret_cast<float4*>(pv + 4 * h);
+      *reinterpret_cast<float4*>(m + base + 4 * h) = *reinterpret_cast<float4*>(mv + 4 * h);
+      *reinterpret_cast<float4*>(v + base + 4 * h) = *reinterpret_cast<float4*>(vv + 4 * h);
+    }
+  } else {
+    for (int i = 0; i < cnt; ++i) { p[base + i] = pv[i]; m[base + i] = mv[i]; v[base + i] = vv[i]; }
+  }
+}
+
+inline int status() {
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ocpg_grad_norm_clip(const long long* grads, const long long* numels, const long long* chunk_prefix, int n, long long total_chunks,
+                        float max_norm, float* partials, float* norm_and_coef, void* stream) {
+  if (n < 0 || total_chunks < 0) return -1004;
+  if (!norm_and_coef) return -1008;
+  hipStream_t st = (hipStream_t)stream;
+  if (n > 0 && total_chunks > 0) {
+    if (!grads || !numels || !chunk_prefix) return -1001;
+    if (!partials) return -1007;
+    if (total_chunks > 2147483647LL) return -1005;
+    sqnorm_partials<<<(unsigned)total_chunks, 256, 0, st>>>(grads, numels, chunk_prefix, n, partials);
+  }
+  norm_finish<<<1, 1024, 0, st>>>(partials, n > 0 ? total_chunks : 0, max_norm, norm_and_coef);
+  return status();
+}
+
+int ocpg_adamw_step(const long long* params, const long long* grads, const long long* exp_avg, const long long* exp_avg_sq,
+                    const long long* numels, const long long* chunk_prefix, const float* lr, const float* weight_decay, int n,
+                    long long total_chunks, const float* norm_and_coef, double beta1, double beta2, double eps, long long step, void* stream) {
+  if (n < 0 || total_chunks < 0 || step < 1) return -1009;
+  if (n == 0 || total_chunks == 0) return 0;
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !numels || !chunk_prefix || !lr || !weight_decay) return -1001;
+  if (total_chunks > 2147483647LL) return -1010;
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  adamw_apply<<<(unsigned)total_chunks, 256, 0, (hipStream_t)stream>>>(params, grads, exp_avg, exp_avg_sq, numels, chunk_prefix, lr, weight_decay, n,
+                                                                       norm_and_coef, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)bc1,
+                                                                       (float)(1.0 / sqrt(bc2)));
+  return status();
+}
+
+}  // extern "C"

@@ -1220,3 +1220,46 @@ def test_bilinear_resize_as_matmul(dev, align, shape, size):
     ga, = torch.autograd.grad((ya * go).sum(), a)
     gb, = torch.autograd.grad((yb * go).sum(), b)
     assert (ga - gb).abs().max().item() <= 2e-5 * gb.abs().max().item() + 1e-6
+
+
+def test_clip_adamw_kernels_equal_torch(dev):
+    """ocpg_amd.optim.ClipAdamW (csrc/adamw.hip: total norm, clip coefficient, AdamW update in three launches) against
+    torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW (engine.py:100-106, main.py:76-99) over four steps: four groups with their own
+    learning rates, odd sizes, a channels-last 4-D parameter, a step where the norm is below the threshold and steps where it clips;
+    the state dict round-trips into a plain torch.optim.AdamW."""
+    from ocpg_amd.optim import ClipAdamW
+    torch.manual_seed(5)
+    shapes = [(257, 33), (64, 32, 3, 3), (5,), (1000, 130), (7, 9, 11), (2049,)]
+
+    def make():
+        ps = [torch.nn.Parameter(torch.randn(s, device=dev)) for s in shapes]
+        ps[1].data = ps[1].data.contiguous(memory_format=torch.channels_last)
+        return ps
+    a = make()
+    b = [torch.nn.Parameter(p.detach().clone(memory_format=torch.preserve_format)) for p in a]
+    groups = lambda ps: [{"params": ps[:2], "lr": 1e-2}, {"params": ps[2:3], "lr": 5e-3}, {"params": ps[3:5], "lr": 1e-3}, {"params": ps[5:], "lr": 2e-2}]   # noqa: E731
+    mine = ClipAdamW(groups(a), lr=1e-2, weight_decay=5e-4)
+    ref = torch.optim.AdamW(groups(b), lr=1e-2, weight_decay=5e-4, foreach=False, fused=False)
+    for it, (scale, max_norm) in enumerate(((1e-4, 0.1), (1.0, 0.1), (3.0, 0.1), (1.0, 0.0))):
+        gs = [torch.randn(s, device=dev) * scale for s in shapes]
+        for p, q, g in zip(a, b, gs):
+            p.grad = g.clone().contiguous(memory_format=torch.channels_last) if g.dim() == 4 else g.clone()
+            q.grad = p.grad.clone(memory_format=torch.preserve_format)
+        norm = mine.step_clip(max_norm)
+        # the reference clips with clip_grad_norm_'s rule, coef = min(1, max_norm / (norm + 1e-6)), on the EXACT norm (fp64): torch's own
+        # fp32 foreach norm of these 170 k elements is ~1e-5 off, which the second moments would show as 2e-5
+        want = torch.sqrt(sum(q.grad.double().square().sum() for q in b))
+        if max_norm > 0:
+            coef = min(1.0, max_norm / (float(want) + 1e-6))
+            for q in b:
+                q.grad.mul_(coef)
+        ref.step()
+        assert abs(float(norm) - float(want)) <= 2e-6 * float(want), (it, float(norm), float(want))
+        for i, (p, q) in enumerate(zip(a, b)):
+            assert torch.allclose(p, q, rtol=2e-6, atol=2e-7), (it, i, (p - q).abs().max().item())
+            for k in ("exp_avg", "exp_avg_sq"):
+                assert torch.allclose(mine.state[p][k], ref.state[q][k], rtol=2e-6, atol=1e-9), (it, i, k)
+    sd = mine.state_dict()
+    assert all(float(v["step"]) == 4.0 for v in sd["state"].values())
+    plain = torch.optim.AdamW(groups([torch.nn.Parameter(p.detach().clone(memory_format=torch.preserve_format)) for p in a]), lr=1e-2, weight_decay=5e-4)
+    plain.load_state_dict(sd)                 # interchangeable with torch's optimizer (checkpoint wire format, row f2)
