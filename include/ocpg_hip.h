@@ -337,6 +337,29 @@ int ocpg_attn_smallk_bwd(const void* q, long long ldq, const void* k, long long 
 int ocpg_window_means3x3_fwd(const float* x, long long planes, int h, int w, int as_bf16, float* out, void* stream);
 int ocpg_window_means3x3_bwd(const float* gm, long long planes, int h, int w, float* dx, void* stream);
 
+/* MSO mask refinement (reference models/decoder.py:14-46; called at models/ocpg.py:375-390 once per decoder layer): all of its
+ * convolutions are 3x3 / padding 1 with <= 16 output channels per group, on CHANNELS-LAST maps (csrc/mso.hip).
+ *   ocpg_mso_conv3x3   out[n,y,x,o] = sum_{tap,c} w[o][tap][c] * act(in[n,y+dy,x+dx,c]) (+ bias[o]) (+ addend[n % NA,y,x,o]), kept
+ *                      where mask[n,y,x,o] > 0 (mask may be NULL), (+ residual[n,y,x,o]).  in [NB,H,W,C] (in_dt), act = ReLU when
+ *                      relu_in; w [co_total][9][C] (w_dt; tap = 3 ky + kx); out [NB,H,W,co_total] (out_dt), any co_total (groups
+ *                      of 16 output channels).  Forward convolutions AND their input gradients (the same convolution with flipped,
+ *                      transposed weights; mask = the input of the ReLU in front of the forward convolution).
+ *   ocpg_mso_wgrad     part[band][o][tap][c] = sum over the band's pixels of g[n,y,x,o] * act(x[n,y+dy,x+dx,c]); x [NB,H,W,C]
+ *                      (x_dt), g [NB,H,W,co] fp32, co <= 16; bands = NB * ceil(H / rows_per_band), rows_per_band from
+ *                      ocpg_mso_wgrad_rows(); the caller sums the bands (the weight gradient).  part_bias (may be NULL)
+ *                      [bands][16]: the band's sum of g per output channel (the bias gradient's partial sums).
+ *   ocpg_bilinear_nhwc_fwd / _bwd   F.interpolate(mode="bilinear", align_corners=False, size=(HO, WO)) of a channels-last fp32
+ *                      map [NB,H,W,C] (C % 4 == 0) and its input gradient (gather form, fully written, no atomics).
+ * compute_dt: 1 / 2 = bf16 / fp16 operands with fp32 accumulation (the autocast convolution), 0 = fp32 operands. */
+int ocpg_mso_conv3x3(const void* in, int in_dt, int relu_in, const void* w, int w_dt, const float* bias, const float* addend, int NA,
+                     const void* mask, int mask_dt, const float* residual, void* out, int out_dt, int NB, int H, int W, int C,
+                     int co_total, int compute_dt, void* stream);
+int ocpg_mso_wgrad_rows(int NB, int H, int C, int compute_dt);
+int ocpg_mso_wgrad(const void* x, int x_dt, int relu_in, const float* g, float* part, float* part_bias, int NB, int H, int W, int C,
+                   int co, int rows_per_band, int compute_dt, void* stream);
+int ocpg_bilinear_nhwc_fwd(const float* in, int NB, int H, int W, int C, int HO, int WO, float* out, void* stream);
+int ocpg_bilinear_nhwc_bwd(const float* gout, int NB, int H, int W, int C, int HO, int WO, float* gin, void* stream);
+
 /* nn.Linear over FEW rows (decoder layers, box / class heads, controller, LFM coefficient MLPs: models/deformable_transformer.py:
  * 313-336, models/ocpg.py:83-110) under autocast, one launch forward and ONE launch backward (csrc/small_linear.hip):
  *   fwd: y [R, Cout] bf16 = act(x [R, Cin] (fp32 when x_f32 != 0, else bf16) . w [Cout, Cin]^T (bf16) + b [Cout] (bf16 or NULL)),

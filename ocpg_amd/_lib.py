@@ -37,6 +37,11 @@ SIGNATURES = {
     "ocpg_gemm_tune_rejected": [],
     "ocpg_window_means3x3_fwd": [_vp, ctypes.c_longlong, _int, _int, _int, _vp, _vp],
     "ocpg_window_means3x3_bwd": [_vp, ctypes.c_longlong, _int, _int, _vp, _vp],
+    "ocpg_mso_conv3x3": [_vp, _int, _int, _vp, _int, _vp, _vp, _int, _vp, _int, _vp, _vp, _int] + [_int] * 6 + [_vp],
+    "ocpg_mso_wgrad_rows": [_int] * 4,
+    "ocpg_mso_wgrad": [_vp, _int, _int, _vp, _vp, _vp] + [_int] * 7 + [_vp],
+    "ocpg_bilinear_nhwc_fwd": [_vp] + [_int] * 6 + [_vp, _vp],
+    "ocpg_bilinear_nhwc_bwd": [_vp] + [_int] * 6 + [_vp, _vp],
     "ocpg_small_linear_fwd": [_vp, _int, _vp, _vp, _int, _int, _int, _int, _vp, _vp],
     "ocpg_small_linear_bwd": [_vp, _int, _vp, _int, _vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp],
     "ocpg_layernorm_blocks": [ctypes.c_longlong],
@@ -92,7 +97,7 @@ SIGNATURES = {
 
 # ---- optional live kernel timing (bench.py): HIP events on the launch stream around every library call ----------
 _TIMING = {"on": False, "events": []}
-_UNTIMED = ("ocpg_colsum_blocks", "ocpg_gemm_plans", "ocpg_gemm_tuned", "ocpg_gemm_tune_rejected", "ocpg_bias_relu_dropout_bwd_slots", "ocpg_dropout_add_ln_bwd_slots", "ocpg_groupnorm_cl_work")
+_UNTIMED = ("ocpg_colsum_blocks", "ocpg_mso_wgrad_rows", "ocpg_gemm_plans", "ocpg_gemm_tuned", "ocpg_gemm_tune_rejected", "ocpg_bias_relu_dropout_bwd_slots", "ocpg_dropout_add_ln_bwd_slots", "ocpg_groupnorm_cl_work")
 
 
 def enable_kernel_timing(on=True):
