@@ -347,7 +347,9 @@ int ocpg_window_means3x3_bwd(const float* gm, long long planes, int h, int w, fl
  *   ocpg_mso_wgrad     part[band][o][tap][c] = sum over the band's pixels of g[n,y,x,o] * act(x[n,y+dy,x+dx,c]); x [NB,H,W,C]
  *                      (x_dt), g [NB,H,W,co] fp32, co <= 16; bands = NB * ceil(H / rows_per_band), rows_per_band from
  *                      ocpg_mso_wgrad_rows(); the caller sums the bands (the weight gradient).  part_bias (may be NULL)
- *                      [bands][16]: the band's sum of g per output channel (the bias gradient's partial sums).
+ *                      [bands][16]: the band's sum of g per output channel (the bias gradient's partial sums).  accumulate != 0:
+ *                      part is [co][9][C] and part_bias [16], both ZEROED BY THE CALLER; every band adds its product with float
+ *                      atomics (one launch, no reduction pass; the summation order is then not reproducible bit for bit).
  *   ocpg_bilinear_nhwc_fwd / _bwd   F.interpolate(mode="bilinear", align_corners=False, size=(HO, WO)) of a channels-last fp32
  *                      map [NB,H,W,C] (C % 4 == 0) and its input gradient (gather form, fully written, no atomics).
  * compute_dt: 1 / 2 = bf16 / fp16 operands with fp32 accumulation (the autocast convolution), 0 = fp32 operands. */
@@ -355,8 +357,8 @@ int ocpg_mso_conv3x3(const void* in, int in_dt, int relu_in, const void* w, int 
                      const void* mask, int mask_dt, const float* residual, void* out, int out_dt, int NB, int H, int W, int C,
                      int co_total, int compute_dt, void* stream);
 int ocpg_mso_wgrad_rows(int NB, int H, int C, int compute_dt);
-int ocpg_mso_wgrad(const void* x, int x_dt, int relu_in, const float* g, float* part, float* part_bias, int NB, int H, int W, int C,
-                   int co, int rows_per_band, int compute_dt, void* stream);
+int ocpg_mso_wgrad(const void* x, int x_dt, int relu_in, const float* g, float* part, float* part_bias, int accumulate, int NB, int H, int W,
+                   int C, int co, int rows_per_band, int compute_dt, void* stream);
 int ocpg_bilinear_nhwc_fwd(const float* in, int NB, int H, int W, int C, int HO, int WO, float* out, void* stream);
 int ocpg_bilinear_nhwc_bwd(const float* gout, int NB, int H, int W, int C, int HO, int WO, float* gin, void* stream);
 

@@ -39,7 +39,7 @@ SIGNATURES = {
     "ocpg_window_means3x3_bwd": [_vp, ctypes.c_longlong, _int, _int, _vp, _vp],
     "ocpg_mso_conv3x3": [_vp, _int, _int, _vp, _int, _vp, _vp, _int, _vp, _int, _vp, _vp, _int] + [_int] * 6 + [_vp],
     "ocpg_mso_wgrad_rows": [_int] * 4,
-    "ocpg_mso_wgrad": [_vp, _int, _int, _vp, _vp, _vp] + [_int] * 7 + [_vp],
+    "ocpg_mso_wgrad": [_vp, _int, _int, _vp, _vp, _vp] + [_int] * 8 + [_vp],
     "ocpg_bilinear_nhwc_fwd": [_vp] + [_int] * 6 + [_vp, _vp],
     "ocpg_bilinear_nhwc_bwd": [_vp] + [_int] * 6 + [_vp, _vp],
     "ocpg_small_linear_fwd": [_vp, _int, _vp, _vp, _int, _int, _int, _int, _vp, _vp],

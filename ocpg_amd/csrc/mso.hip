@@ -14,8 +14,8 @@
 //   k_wgrad_n16  gw[o][tap][c] = sum_{n,y,x} g[n,y,x,o] * act(x[n, y+dy, x+dx, c]): the reduction axis is the PIXEL, so the
 //                fragments take 4 consecutive pixels of one channel (4 16-bit LDS reads); a workgroup owns (a band of rows of one
 //                image) x (64 / 32 / 16 input channels), its 4 waves split (channel group) x (tile rows), keep their 9 x 16 x 16
-//                tiles in registers over the whole band and write them once as a partial product [band][o][tap][c] (summed by the
-//                caller: <= 9 MB) together with the band's sum of g (the bias gradient).
+//                tiles in registers over the whole band and add them once (float atomics: <= 2.2 M per launch) to the weight gradient
+//                [o][tap][c] -- or write them as a partial product per band -- together with the band's sum of g (the bias gradient).
 //   k_up_fwd/bwd bilinear resize (align_corners=False, reference decoder.py:38) of a channels-last fp32 map; the backward is a
 //                gather over the <= 6 x 6 output pixels that can touch an input pixel (no atomics).
 // Compute type = the autocast dtype (bf16 / fp16 operands, fp32 accumulation, as the reference's autocast convolutions) or fp32
@@ -390,9 +390,9 @@ template <int DT, int CK, int KS, bool XW> __global__ __launch_bounds__(256, (CK
 struct WgP {
   const void* x;           // [NB, H, W, C]
   const float* g;          // [NB, H, W, co]
-  float* part;             // [bands][co][9][C]
-  float* part_b;           // [bands][16] | null: the band's sum of g per output channel
-  int x_dt, relu_in;
+  float* part;             // [bands][co][9][C]; accumulate: [co][9][C], zeroed by the caller, float atomics
+  float* part_b;           // [bands][16] (accumulate: [16]) | null: the band's sum of g per output channel
+  int x_dt, relu_in, accumulate;
   int NB, H, W, C, co, RB, bands_per_img;
 };
 
@@ -533,8 +533,12 @@ template <int DT, int NCG, bool XW> __global__ __launch_bounds__(256, (DT == F32
       atomicAdd(&redb[tid & 15], bs[0]);
     }
     __syncthreads();
-    if (tid < 16) p.part_b[(size_t)band * 16 + tid] = redb[tid];
+    if (tid < 16) {
+      if (p.accumulate) unsafeAtomicAdd(p.part_b + tid, redb[tid]);
+      else p.part_b[(size_t)band * 16 + tid] = redb[tid];
+    }
   }
+  const size_t pb = p.accumulate ? 0 : (size_t)band * co * 9 * C;
 
   // acc[tap][i] = gw[o = 4 g + i][tap][c = c0 + 16 cg + col] of this wave's rows
   if constexpr (RS > 1) {
@@ -551,7 +555,11 @@ template <int DT, int NCG, bool XW> __global__ __launch_bounds__(256, (DT == F32
     for (int i = tid; i < NCG * 9 * 256; i += 256) {
       const int cc = i & 15, o = (i >> 4) & 15, tap = (i >> 8) % 9, gcg = i / (9 * 256);
       const int c = c0 + gcg * 16 + cc;
-      if (o < co && c < C) p.part[(((size_t)band * co + o) * 9 + tap) * C + c] = red[i];
+      if (o < co && c < C) {
+        float* d = p.part + pb + ((size_t)o * 9 + tap) * C + c;
+        if (p.accumulate) unsafeAtomicAdd(d, red[i]);
+        else *d = red[i];
+      }
     }
   } else {
     const int c = c0 + cg * 16 + col;
@@ -562,7 +570,11 @@ template <int DT, int NCG, bool XW> __global__ __launch_bounds__(256, (DT == F32
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int o = 4 * g + i;
-          if (o < co) p.part[(((size_t)band * co + o) * 9 + tap) * C + c] = v[i];
+          if (o < co) {
+            float* d = p.part + pb + ((size_t)o * 9 + tap) * C + c;
+            if (p.accumulate) unsafeAtomicAdd(d, v[i]);
+            else *d = v[i];
+          }
         }
       }
     }
@@ -691,8 +703,8 @@ extern "C" int ocpg_mso_wgrad_rows(int NB, int H, int C, int compute_dt) {
   return rb;
 }
 
-extern "C" int ocpg_mso_wgrad(const void* x, int x_dt, int relu_in, const float* g, float* part, float* part_bias, int NB, int H, int W, int C,
-                              int co, int rows_per_band, int compute_dt, void* stream) {
+extern "C" int ocpg_mso_wgrad(const void* x, int x_dt, int relu_in, const float* g, float* part, float* part_bias, int accumulate, int NB, int H,
+                              int W, int C, int co, int rows_per_band, int compute_dt, void* stream) {
   if (NB < 0 || H < 1 || W < 1 || C < 1 || co < 1 || co > 16 || rows_per_band < 8 || rows_per_band % 8) return -1002;
   if (NB == 0) return 0;
   if (!x) return -1001;
@@ -700,7 +712,7 @@ extern "C" int ocpg_mso_wgrad(const void* x, int x_dt, int relu_in, const float*
   if (!part) return -1005;
   if (!check_dt(x_dt) || !check_dt(compute_dt)) return -1003;
   WgP p;
-  p.x = x, p.g = g, p.part = part, p.part_b = part_bias, p.x_dt = x_dt, p.relu_in = relu_in;
+  p.x = x, p.g = g, p.part = part, p.part_b = part_bias, p.x_dt = x_dt, p.relu_in = relu_in, p.accumulate = accumulate;
   p.NB = NB, p.H = H, p.W = W, p.C = C, p.co = co, p.RB = rows_per_band, p.bands_per_img = (H + rows_per_band - 1) / rows_per_band;
   const long long bands = (long long)NB * p.bands_per_img;
   if (bands > 0x7fffffffLL) return -1002;

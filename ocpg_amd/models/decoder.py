@@ -11,7 +11,7 @@ from torch import nn
 
 from . import amp_cache, fallbacks
 from .amp_cache import lookup
-from .ops.functions.mso_func import bilinear_nhwc, compute_code, conv3x3_n16
+from .ops.functions.mso_func import bilinear_nhwc, compute_code, conv3x3_n16, res_block_n16
 from .resample import bilinear_resize
 
 MATMUL_BILINEAR = True       # A/B switch: bilinear resampling as two matrix products (no atomics backward)
@@ -67,8 +67,7 @@ class MSO(nn.Module):
                 p = bilinear_nhwc(p, f.shape[-2:])
             w1 = lookup(conv1.weight)
             shared = conv3x3_n16(_nhwc(f), _tap_major(w1[:, c:], cdt), _bias32(conv1.bias), relu_in=True, cdt=cdt)          # [bt, H, W, 16]
-            y = conv3x3_n16(p, _tap_major(w1[:, :c], cdt), addend=shared, relu_in=True, cdt=cdt)
-            p = conv3x3_n16(y, _tap_major(lookup(conv2.weight), cdt), _bias32(conv2.bias), residual=p, relu_in=True, cdt=cdt)
+            p = res_block_n16(p, shared, _tap_major(w1[:, :c], cdt), _tap_major(lookup(conv2.weight), cdt), _bias32(conv2.bias), cdt)
         out = conv3x3_n16(p, _tap_major(lookup(self.out_conv.weight), cdt), _bias32(self.out_conv.bias), cdt=cdt)             # [N, 2h, 2w, 1]
         return out.permute(0, 3, 1, 2)
 

@@ -95,6 +95,36 @@ def test_conv3x3_n16_forward_backward(dev, case, dt):
         assert err <= gtol * s, (name, err, s)
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("atomic", [True, False])
+def test_res_block_equals_two_convolutions(dev, dt, atomic, monkeypatch):
+    """ResBlockN16 (one node, skip gradient added in the input-gradient kernel's epilogue) == the two Conv3x3N16 nodes it fuses, in
+    both weight-gradient modes (bands added with atomics / partial products summed)."""
+    from ocpg_amd.models.ops.functions import mso_func as m
+    monkeypatch.setattr(m, "WGRAD_ATOMIC", atomic)
+    g = torch.Generator().manual_seed(3)
+    nb, na, h, w, c = 6, 2, 19, 27, 16
+    p = torch.randn(nb, h, w, c, generator=g).to(dev)
+    sh = torch.randn(na, h, w, c, generator=g).to(dev)
+    wm = (torch.randn(c, 9, c, generator=g) / 12).to(dt).to(dev)
+    w2 = (torch.randn(c, 9, c, generator=g) / 12).to(dt).to(dev)
+    b2 = torch.randn(c, generator=g).to(dev)
+    go = torch.randn(nb, h, w, c, generator=g).to(dev)
+    res = []
+    for fused in (True, False):
+        leaves = [t.clone().requires_grad_(True) for t in (p, sh, wm, w2, b2)]
+        if fused:
+            out = m.res_block_n16(*leaves, CODES[dt])
+        else:
+            y = m.conv3x3_n16(leaves[0], leaves[2], None, leaves[1], None, True, CODES[dt])
+            out = m.conv3x3_n16(y, leaves[3], leaves[4], None, leaves[0], True, CODES[dt])
+        out.backward(go)
+        res.append([out.detach()] + [t.grad for t in leaves])
+    for a, b, name in zip(res[0], res[1], ("out", "p", "shared", "wm", "w2", "b2")):
+        tol = 2e-5 if a.dtype == torch.float32 else 8e-3
+        assert (a.float() - b.float()).abs().max().item() <= tol * b.float().abs().max().item(), name
+
+
 @pytest.mark.parametrize("shape", [(3, 12, 20, 16, 24, 40), (2, 13, 7, 16, 25, 13), (1, 5, 9, 8, 15, 31), (2, 48, 80, 16, 96, 160)])
 def test_bilinear_nhwc_equals_interpolate(dev, shape):
     from ocpg_amd.models.ops.functions.mso_func import bilinear_nhwc
