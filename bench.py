@@ -515,6 +515,10 @@ LIB_WORK = {
     "ocpg_dropout_add_ln_bwd": ("hbm", lambda a: a[6] * a[7] * (4 + _esz(a[11]) + 4 + (_esz(a[11]) if a[12] else 0) + (4 if a[13] else 0))),
     "ocpg_bias_relu_dropout_fwd": ("hbm", lambda a: a[2] * a[3] * _esz(a[7]) * 2),
     "ocpg_bias_relu_dropout_bwd": ("hbm", lambda a: a[2] * a[3] * _esz(a[5]) * 3),
+    # MSO (csrc/mso.hip): every map once -- input, output, the optional mask / residual / shared addend; weight gradient: x and g
+    "ocpg_mso_conv3x3": ("hbm", lambda a: a[13] * a[14] * a[15] * (a[16] * _esz(a[1]) + a[17] * (_esz(a[12]) + (_esz(a[9]) if a[8] else 0)
+                                                                  + (4 if a[10] else 0))) + (a[7] * a[14] * a[15] * a[17] * 4 if a[6] else 0)),
+    "ocpg_mso_wgrad": ("hbm", lambda a: a[7] * a[8] * a[9] * (a[10] * _esz(a[1]) + a[11] * 4)),
     "ocpg_dynmask_fwd_f32": ("valu", lambda a: a[3] * a[4] * a[6] * a[7] * (2 * 16 * (a[5] + 2) + 2 * 16 * 16)),
     "ocpg_dynmask_bwd_f32": ("valu", lambda a: 2 * a[3] * a[4] * a[6] * a[7] * (2 * 16 * (a[5] + 2) + 2 * 16 * 16)),
     # matrix-core kernels: FLOPs = 2 * M * N * K (* batch); bf16 / fp16 storage -> the 2.5 PF peak, fp32 GEMMs -> the 157 TF fp32 peak

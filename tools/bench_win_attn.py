@@ -14,7 +14,7 @@ def run(name, bw, n, h, dtype, iters=10):
     nw = region.shape[0]
     go = torch.randn(bw, n, h * 32, device=dev, generator=g).to(dtype)
     out = {}
-    for mode in ("0", "1"):
+    for mode in os.environ.get("WIN_ATTN_MODES", "0,1").split(","):
         os.environ["OCPG_WIN_ATTN_MFMA"] = mode
         for _ in range(3):
             o = window_attention(qkv, bias, region, 32 ** -0.5, nw); o.backward(go)
@@ -27,10 +27,14 @@ def run(name, bw, n, h, dtype, iters=10):
             tf += e[0].elapsed_time(e[1]); tb += e[1].elapsed_time(e[2])
         out[mode] = (tf / iters * 1e3, tb / iters * 1e3)
     flops = 4.0 * bw * h * n * n * 32
+    out.setdefault("0", (float("nan"), float("nan")))
+    out.setdefault("1", (float("nan"), float("nan")))
     print(f"{name:28s} bw={bw:5d} N={n} H={h:2d}: fwd valu {out['0'][0]:7.1f} us  mfma {out['1'][0]:7.1f} us ({flops / out['1'][0] / 1e6:6.1f} TFLOP/s) | "
           f"bwd valu {out['0'][1]:7.1f} us  mfma {out['1'][1]:7.1f} us", flush=True)
-run("swin-t stage1 (bf16)", 644, 245, 3, torch.bfloat16)
-run("swin-t stage2 (bf16)", 168, 245, 6, torch.bfloat16)
-run("swin-t stage3 (bf16)", 48, 245, 12, torch.bfloat16)
-run("swin-t stage4 (bf16)", 12, 245, 24, torch.bfloat16)
-run("swin-b stage1 (fp16, N=392)", 270, 392, 4, torch.float16)
+SHAPES = [("swin-t stage1 (bf16)", 644, 245, 3, torch.bfloat16), ("swin-t stage2 (bf16)", 168, 245, 6, torch.bfloat16),
+          ("swin-t stage3 (bf16)", 48, 245, 12, torch.bfloat16), ("swin-t stage4 (bf16)", 12, 245, 24, torch.bfloat16),
+          ("swin-b stage1 (fp16, N=392)", 270, 392, 4, torch.float16)]
+only = os.environ.get("WIN_ATTN_ONLY")          # substring of the shape's name (PMC passes: one shape, one mode)
+for sh in SHAPES:
+    if not only or only in sh[0]:
+        run(*sh)
