@@ -65,58 +65,88 @@ __global__ __launch_bounds__(1024) void norm_finish(const float* __restrict__ pa
   }
 }
 
+constexpr int GROUP = 4;        // table chunks per workgroup: 4 x (4 reads + 3 writes) of 32 B per lane in flight
+
 __global__ __launch_bounds__(256) void adamw_apply(const long long* __restrict__ params, const long long* __restrict__ grads,
                                                    const long long* __restrict__ exp_avg, const long long* __restrict__ exp_avg_sq,
                                                    const long long* __restrict__ numels, const long long* __restrict__ chunk_prefix,
-                                                   const float* __restrict__ lr, const float* __restrict__ wd, int n, const float* __restrict__ clip,
-                                                   float om_beta1, float beta2, float om_beta2, float eps, float bc1, float rsqrt_bc2) {
-  const long long blk = blockIdx.x;
-  const int t = find_tensor(chunk_prefix, n, blk);
-  float* p = reinterpret_cast<float*>(params[t]);
-  const float* g = reinterpret_cast<const float*>(grads[t]);
-  float* m = reinterpret_cast<float*>(exp_avg[t]);
-  float* v = reinterpret_cast<float*>(exp_avg_sq[t]);
-  const long long count = numels[t];
-  const float lr_t = lr[t], decay = 1.f - lr_t * wd[t], step_size = lr_t / bc1, coef = clip ? clip[1] : 1.f;
-  const long long base = (blk - chunk_prefix[t]) * CHUNK + (long long)threadIdx.x * 8;
-  if (base >= count) return;
-  const bool wide = base + 8 <= count && ((reinterpret_cast<uintptr_t>(p + base) | reinterpret_cast<uintptr_t>(g + base) |
-                                           reinterpret_cast<uintptr_t>(m + base) | reinterpret_cast<uintptr_t>(v + base)) & 15) == 0;
-  float pv[8], gv[8], mv[8], vv[8];
-  const int cnt = wide ? 8 : (int)((count - base) < 8 ? (count - base) : 8);
-  if (wide) {
+                                                   const float* __restrict__ lr, const float* __restrict__ wd, int n, long long total_chunks,
+                                                   const float* __restrict__ clip, float om_beta1, float beta2, float om_beta2, float eps, float bc1,
+                                                   float rsqrt_bc2) {
+  const long long blk0 = (long long)blockIdx.x * GROUP;
+  const float coef = clip ? clip[1] : 1.f;
+  int t = find_tensor(chunk_prefix, n, blk0);
+  float pv[GROUP][8], gv[GROUP][8], mv[GROUP][8], vv[GROUP][8];
+  float* pp[GROUP];
+  float* mp[GROUP];
+  float* vp[GROUP];
+  float decay[GROUP], step_size[GROUP];
+  int cnt[GROUP];
+  bool wide[GROUP];
+  // ---- all loads of the group first
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      *reinterpret_cast<float4*>(pv + 4 * h) = *reinterpret_cast<const float4*>(p + base + 4 * h);
-      *reinterpret_cast<float4*>(gv + 4 * h) = *reinterpret_cast<const float4*>(g + base + 4 * h);
-      *reinterpret_cast<float4*>(mv + 4 * h) = *reinterpret_cast<const float4*>(m + base + 4 * h);
-      *reinterpret_cast<float4*>(vv + 4 * h) = *reinterpret_cast<const float4*>(v + base + 4 * h);
+  for (int q = 0; q < GROUP; ++q) {
+    const long long blk = blk0 + q;
+    cnt[q] = 0;
+    wide[q] = false;
+    if (blk >= total_chunks) continue;
+    while (t + 1 < n && chunk_prefix[t + 1] <= blk) ++t;        // chunks of one tensor are consecutive: at most a step or two
+    float* p = reinterpret_cast<float*>(params[t]);
+    const float* g = reinterpret_cast<const float*>(grads[t]);
+    float* m = reinterpret_cast<float*>(exp_avg[t]);
+    float* v = reinterpret_cast<float*>(exp_avg_sq[t]);
+    const long long count = numels[t];
+    const float lr_t = lr[t];
+    decay[q] = 1.f - lr_t * wd[t];
+    step_size[q] = lr_t / bc1;
+    const long long base = (blk - chunk_prefix[t]) * CHUNK + (long long)threadIdx.x * 8;
+    if (base >= count) continue;
+    pp[q] = p + base, mp[q] = m + base, vp[q] = v + base;
+    wide[q] = base + 8 <= count && ((reinterpret_cast<uintptr_t>(p + base) | reinterpret_cast<uintptr_t>(g + base) |
+                                     reinterpret_cast<uintptr_t>(m + base) | reinterpret_cast<uintptr_t>(v + base)) & 15) == 0;
+    cnt[q] = wide[q] ? 8 : (int)((count - base) < 8 ? (count - base) : 8);
+    if (wide[q]) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        *reinterpret_cast<float4*>(pv[q] + 4 * h) = *reinterpret_cast<const float4*>(p + base + 4 * h);
+        *reinterpret_cast<float4*>(gv[q] + 4 * h) = *reinterpret_cast<const float4*>(g + base + 4 * h);
+        *reinterpret_cast<float4*>(mv[q] + 4 * h) = *reinterpret_cast<const float4*>(m + base + 4 * h);
+        *reinterpret_cast<float4*>(vv[q] + 4 * h) = *reinterpret_cast<const float4*>(v + base + 4 * h);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (i < cnt[q]) { pv[q][i] = p[base + i]; gv[q][i] = g[base + i]; mv[q][i] = m[base + i]; vv[q][i] = v[base + i]; }
     }
-  } else {
-    for (int i = 0; i < cnt; ++i) { pv[i] = p[base + i]; gv[i] = g[base + i]; mv[i] = m[base + i]; vv[i] = v[base + i]; }
   }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    if (i < cnt) {
-      const float gi = gv[i] * coef;
-      float pi = pv[i] * decay;
-      // (1 - beta) comes from the host in double precision, as torch's Python scalars do: 1.f - 0.999f is 4.7e-5 off 0.001
-      const float mi = mv[i] + (gi - mv[i]) * om_beta1;               // lerp form, as torch: exp_avg.lerp_(grad, 1 - beta1)
-      const float vi = vv[i] * beta2 + gi * gi * om_beta2;            // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
-      const float denom = sqrtf(vi) * rsqrt_bc2 + eps;
-      pi -= step_size * (mi / denom);
-      pv[i] = pi; mv[i] = mi; vv[i] = vi;
-    }
-  }
-  if (wide) {
+  for (int q = 0; q < GROUP; ++q) {
+    if (cnt[q] == 0) continue;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      *reinterpret_cast<float4*>(p + base + 4 * h) = *reinterpret_cast<float4*>(pv + 4 * h);
-      *reinterpret_cast<float4*>(m + base + 4 * h) = *reinterpret_cast<float4*>(mv + 4 * h);
-      *reinterpret_cast<float4*>(v + base + 4 * h) = *reinterpret_cast<float4*>(vv + 4 * h);
+    for (int i = 0; i < 8; ++i) {
+      if (i < cnt[q]) {
+        const float gi = gv[q][i] * coef;
+        float pi = pv[q][i] * decay[q];
+        // (1 - beta) comes from the host in double precision, as torch's Python scalars do: 1.f - 0.999f is 4.7e-5 off 0.001
+        const float mi = mv[q][i] + (gi - mv[q][i]) * om_beta1;            // lerp form, as torch: exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = vv[q][i] * beta2 + gi * gi * om_beta2;            // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+        const float denom = sqrtf(vi) * rsqrt_bc2 + eps;
+        pi -= step_size[q] * (mi / denom);
+        pv[q][i] = pi; mv[q][i] = mi; vv[q][i] = vi;
+      }
     }
-  } else {
-    for (int i = 0; i < cnt; ++i) { p[base + i] = pv[i]; m[base + i] = mv[i]; v[base + i] = vv[i]; }
+    if (wide[q]) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        *reinterpret_cast<float4*>(pp[q] + 4 * h) = *reinterpret_cast<float4*>(pv[q] + 4 * h);
+        *reinterpret_cast<float4*>(mp[q] + 4 * h) = *reinterpret_cast<float4*>(mv[q] + 4 * h);
+        *reinterpret_cast<float4*>(vp[q] + 4 * h) = *reinterpret_cast<float4*>(vv[q] + 4 * h);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (i < cnt[q]) { pp[q][i] = pv[q][i]; mp[q][i] = mv[q][i]; vp[q][i] = vv[q][i]; }
+    }
   }
 }
 
@@ -152,8 +182,8 @@ int ocpg_adamw_step(const long long* params, const long long* grads, const long 
   if (!params || !grads || !exp_avg || !exp_avg_sq || !numels || !chunk_prefix || !lr || !weight_decay) return -1001;
   if (total_chunks > 2147483647LL) return -1010;
   const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
-  adamw_apply<<<(unsigned)total_chunks, 256, 0, (hipStream_t)stream>>>(params, grads, exp_avg, exp_avg_sq, numels, chunk_prefix, lr, weight_decay, n,
-                                                                       norm_and_coef, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)bc1,
+  adamw_apply<<<(unsigned)((total_chunks + GROUP - 1) / GROUP), 256, 0, (hipStream_t)stream>>>(params, grads, exp_avg, exp_avg_sq, numels, chunk_prefix, lr,
+                                                                                              weight_decay, n, total_chunks, norm_and_coef, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)bc1,
                                                                        (float)(1.0 / sqrt(bc2)));
   return status();
 }

@@ -45,17 +45,36 @@ __global__ __launch_bounds__(256) void multi_cast_sum(const long long* __restric
   const long long count = numels[lo], stride = strides[lo];
   long long ns = splits[lo];
   const long long base = (blk - chunk_prefix[lo]) * CHUNK + (long long)threadIdx.x * 8;
-  if (base >= count) return;
   if (ns >> 40) {             // bit 40: THIS tensor's slices are fp32 whatever S is (bias-gradient partials of ocpg_colsum_partials)
+    // few elements (a bias), many slices: the whole workgroup walks the slices -- thread = (element, group of slices), consecutive
+    // threads on consecutive elements (a thread per 8 elements left 32 lanes with 8 x ns dependent scalar loads each: the launch's tail)
     ns &= (1LL << 40) - 1;
     const float* sf = reinterpret_cast<const float*>(srcs[lo]);
-    for (long long i = base; i < base + 8 && i < count; ++i) {
-      float a = 0.f;
-      for (long long k = 0; k < ns; ++k) a += sf[k * stride + i];
-      d[i] = from_f<D>(a);
+    __shared__ float accs[CHUNK];
+    const long long cb = (blk - chunk_prefix[lo]) * CHUNK;
+    const int cnt = (int)(count - cb < CHUNK ? count - cb : CHUNK);
+    for (int i = threadIdx.x; i < cnt; i += 256) accs[i] = 0.f;
+    __syncthreads();
+    int groups = CHUNK / cnt;                 // slices are dealt round-robin to the groups
+    if (groups > ns) groups = (int)ns;
+    for (int w = threadIdx.x; w < cnt * groups; w += 256) {
+      const int e = w % cnt, gk = w / cnt;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      long long k = gk;
+      for (; k + 3LL * groups < ns; k += 4LL * groups) {
+        a0 += sf[k * stride + cb + e];
+        a1 += sf[(k + groups) * stride + cb + e];
+        a2 += sf[(k + 2LL * groups) * stride + cb + e];
+        a3 += sf[(k + 3LL * groups) * stride + cb + e];
+      }
+      for (; k < ns; k += groups) a0 += sf[k * stride + cb + e];
+      atomicAdd(&accs[e], (a0 + a1) + (a2 + a3));
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < cnt; i += 256) d[cb + i] = from_f<D>(accs[i]);
     return;
   }
+  if (base >= count) return;
   const bool wide = base + 8 <= count && ((reinterpret_cast<uintptr_t>(s + base) | reinterpret_cast<uintptr_t>(d + base)) & 15) == 0 &&
                     (ns == 1 || (stride * (long long)sizeof(S)) % 16 == 0);
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -151,7 +170,7 @@ __global__ __launch_bounds__(256) void colsum_partials(const S* __restrict__ x, 
 extern "C" long long ocpg_colsum_blocks(long long R) {
   if (R <= 0) return 0;
   const long long want = (R + 127) / 128;
-  return want < 512 ? want : 512;
+  return want < 128 ? want : 128;          // the partial rows are folded by ONE workgroup per 2048 columns (multi_cast_sum): keep them few
 }
 
 extern "C" int ocpg_colsum_partials(const void* x, long long R, int C, int dtype, float* part, void* stream) {
