@@ -67,27 +67,36 @@ __device__ __forceinline__ void ld16(short (&v)[16], const void* p, int is_f32, 
   }
 }
 
-// stage a T x T tile of a row-major matrix into LDS as [tile row][tile col] (reduction axis = columns)
-__device__ __forceinline__ void stage_plain(short* dst, const void* src, int is_f32, long long ld, int r0, int c0, int rows, int cols,
-                                            const short* mask = nullptr) {
+// A thread's share of one staged T x T tile: 16 consecutive elements of tile row threadIdx.x >> 2 (as bf16 bits)
+struct Seg {
+  bf16x8 a, b;
+};
+
+__device__ __forceinline__ Seg load_seg(const void* src, int is_f32, long long ld, int r0, int c0, int rows, int cols, const short* mask = nullptr) {
   const int row = threadIdx.x >> 2, seg = threadIdx.x & 3;
   short v[16];
   ld16(v, src, is_f32, ld, r0 + row, c0 + seg * 16, rows, cols, mask);
-  bf16x8 a, b;
+  Seg s;
 #pragma unroll
-  for (int u = 0; u < 8; ++u) { a[u] = v[u]; b[u] = v[8 + u]; }
-  *reinterpret_cast<bf16x8*>(dst + row * LROW + seg * 16) = a;
-  *reinterpret_cast<bf16x8*>(dst + row * LROW + seg * 16 + 8) = b;
+  for (int u = 0; u < 8; ++u) { s.a[u] = v[u]; s.b[u] = v[8 + u]; }
+  return s;
 }
 
-// stage a T x T tile TRANSPOSED: LDS [tile col][tile row] (reduction axis = rows of the source)
-__device__ __forceinline__ void stage_transposed(short* dst, const void* src, int is_f32, long long ld, int r0, int c0, int rows, int cols,
-                                                 const short* mask = nullptr) {
+// park it as [tile row][tile col] (reduction axis = columns of the source)
+__device__ __forceinline__ void commit_plain(short* dst, const Seg& s) {
   const int row = threadIdx.x >> 2, seg = threadIdx.x & 3;
-  short v[16];
-  ld16(v, src, is_f32, ld, r0 + row, c0 + seg * 16, rows, cols, mask);
+  *reinterpret_cast<bf16x8*>(dst + row * LROW + seg * 16) = s.a;
+  *reinterpret_cast<bf16x8*>(dst + row * LROW + seg * 16 + 8) = s.b;
+}
+
+// park it TRANSPOSED: LDS [tile col][tile row] (reduction axis = rows of the source)
+__device__ __forceinline__ void commit_transposed(short* dst, const Seg& s) {
+  const int row = threadIdx.x >> 2, seg = threadIdx.x & 3;
 #pragma unroll
-  for (int u = 0; u < 16; ++u) dst[(seg * 16 + u) * LROW + row] = v[u];
+  for (int u = 0; u < 8; ++u) {
+    dst[(seg * 16 + u) * LROW + row] = s.a[u];
+    dst[(seg * 16 + 8 + u) * LROW + row] = s.b[u];
+  }
 }
 
 // one K step (64) of the 64 x 64 tile product: wave (wm, wn) owns the 32 x 32 block
@@ -98,6 +107,31 @@ __device__ __forceinline__ f32x16 tile_mma(const short* As, const short* Bs, f32
     const bf16x8 a = *reinterpret_cast<const bf16x8*>(As + (wm * 32 + fr) * LROW + kk * 16 + fh * 8);
     const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bs + (wn * 32 + fr) * LROW + kk * 16 + fh * 8);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// The K loop: the global loads of PF consecutive K steps are issued back to back, then the steps are parked and multiplied one by
+// one -- these launches are a chain of (load latency -> barrier -> 4 MFMAs) per step and nothing else runs on the CU, so the latency
+// is paid once per PF steps instead of once per step (Cin = 256: 1 instead of 4; the FFN's 1024: 4 instead of 16).
+constexpr int PF = 4;
+template <bool TA, bool TB, typename LA, typename LB>
+__device__ __forceinline__ f32x16 k_loop(int nk, short* As, short* Bs, LA load_a, LB load_b, f32x16 acc) {
+  for (int kb = 0; kb < nk; kb += PF) {
+    Seg sa[PF], sb[PF];
+#pragma unroll
+    for (int j = 0; j < PF; ++j)
+      if (kb + j < nk) { sa[j] = load_a((kb + j) * T); sb[j] = load_b((kb + j) * T); }
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+      if (kb + j < nk) {
+        if (TA) commit_transposed(As, sa[j]); else commit_plain(As, sa[j]);
+        if (TB) commit_transposed(Bs, sb[j]); else commit_plain(Bs, sb[j]);
+        __syncthreads();
+        acc = tile_mma(As, Bs, acc);
+        __syncthreads();
+      }
+    }
   }
   return acc;
 }
@@ -128,13 +162,8 @@ __global__ __launch_bounds__(NT) void sl_fwd(const void* __restrict__ x, int x_f
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  for (int k0 = 0; k0 < Cin; k0 += T) {
-    stage_plain(As, x, x_f32, Cin, m0, k0, R, Cin);
-    stage_plain(Bs, w, 0, Cin, n0, k0, Cout, Cin);
-    __syncthreads();
-    acc = tile_mma(As, Bs, acc);
-    __syncthreads();
-  }
+  acc = k_loop<false, false>((Cin + T - 1) / T, As, Bs, [&](int k0) { return load_seg(x, x_f32, Cin, m0, k0, R, Cin); },
+                             [&](int k0) { return load_seg(w, 0, Cin, n0, k0, Cout, Cin); }, acc);
   store_tile(y, 0, Cout, m0, n0, R, Cout, acc, b, relu);
 }
 
@@ -150,25 +179,17 @@ __global__ __launch_bounds__(NT) void sl_bwd(const void* __restrict__ gy, int gy
   if ((int)blockIdx.x < n_dx) {
     if (!need_gx) return;
     const int m0 = (blockIdx.x / ntn) * T, n0 = (blockIdx.x % ntn) * T;
-    for (int k0 = 0; k0 < Cout; k0 += T) {
-      stage_plain(As, gy, gy_f32, Cout, m0, k0, R, Cout, ymask);        // A[m = r][k = co]
-      stage_transposed(Bs, w, 0, Cin, k0, n0, Cout, Cin);               // B[n = ci][k = co] = w[co][ci]
-      __syncthreads();
-      acc = tile_mma(As, Bs, acc);
-      __syncthreads();
-    }
+    // A[m = r][k = co] = gy;  B[n = ci][k = co] = w[co][ci]
+    acc = k_loop<false, true>((Cout + T - 1) / T, As, Bs, [&](int k0) { return load_seg(gy, gy_f32, Cout, m0, k0, R, Cout, ymask); },
+                              [&](int k0) { return load_seg(w, 0, Cin, k0, n0, Cout, Cin); }, acc);
     store_tile(gx, x_f32, Cin, m0, n0, R, Cin, acc, nullptr);
   } else {
     const int t = blockIdx.x - n_dx;
     const int m0 = (t / ntn) * T, n0 = (t % ntn) * T;                   // m = co, n = ci
     const bool do_bias = gb && (t % ntn) == 0;
-    for (int k0 = 0; k0 < R; k0 += T) {
-      stage_transposed(As, gy, gy_f32, Cout, k0, m0, R, Cout, ymask);   // A[m = co][k = r] = gy[r][co]
-      stage_transposed(Bs, x, x_f32, Cin, k0, n0, R, Cin);              // B[n = ci][k = r] = x[r][ci]
-      __syncthreads();
-      acc = tile_mma(As, Bs, acc);
-      __syncthreads();
-    }
+    // A[m = co][k = r] = gy[r][co];  B[n = ci][k = r] = x[r][ci]
+    acc = k_loop<true, true>((R + T - 1) / T, As, Bs, [&](int k0) { return load_seg(gy, gy_f32, Cout, k0, m0, R, Cout, ymask); },
+                             [&](int k0) { return load_seg(x, x_f32, Cin, k0, n0, R, Cin); }, acc);
     store_tile(gw, 0, Cin, m0, n0, Cout, Cin, acc, nullptr);
     if (do_bias) {
       // bias gradient = column sum of gy in fp32 from the ORIGINAL values (ATen reduces the fp32 gradient before the cast; summing
