@@ -34,7 +34,7 @@ constexpr int LDS_ROW = BK + 8;        // bf16 elements per LDS row (144 B: 16-B
 constexpr int SEGS = BK / 8;           // 16-B segments per staged row
 constexpr int ROWS_PER_PASS = NT / SEGS;
 constexpr int A_L = BM / ROWS_PER_PASS;   // 16-B loads per thread per K step (B: BN / ROWS_PER_PASS)
-constexpr int NSETS = 2;               // register sets in flight
+constexpr int NSETS = 3;               // register sets in flight
 
 struct ConvGeom {
   int N, H, W, C;          // rows' map: output map (forward) or input map (dgrad); C = channels of the GATHERED operand
@@ -64,9 +64,16 @@ template <bool DGRAD, int BN>
 __global__ __launch_bounds__(NT) void conv3x3_mfma(const __hip_bfloat16* __restrict__ x, const __hip_bfloat16* __restrict__ w,
                                                    const float* __restrict__ scale, const float* __restrict__ bias, int relu, ConvGeom g,
                                                    __hip_bfloat16* __restrict__ y) {
-  __shared__ __attribute__((aligned(16))) short As[2][BM * LDS_ROW];
   constexpr int B_L = BN / ROWS_PER_PASS, NJ = BN / 64, WN = BN / 2;      // a wave's tile: 32 rows x WN columns = NJ MFMA tiles
-  __shared__ __attribute__((aligned(16))) short Bs[2][BN * LDS_ROW];
+  // 64-column tiles: the four waves split the K STEP instead of the tile (wave w takes the 16-wide slice w of every 64-wide step and
+  // accumulates the whole 64 x 64 tile = 2 x 2 MFMA tiles): two A and two B fragments feed four MFMAs, where a 32 x 32 wave tile reads
+  // two fragments per MFMA -- the kernel was bound by LDS read bandwidth (32 KB of fragment reads per workgroup and K step against
+  // 16 KB of global data), not by the matrix cores or HBM.  The four partial tiles are summed through LDS once, after the K loop.
+  constexpr bool KSPLIT = BN == 64;
+  constexpr int NACC = KSPLIT ? 4 : NJ;
+  __shared__ __attribute__((aligned(16))) short smem[2 * BM * LDS_ROW + 2 * BN * LDS_ROW];
+  short (*As)[BM * LDS_ROW] = reinterpret_cast<short (*)[BM * LDS_ROW]>(smem);
+  short (*Bs)[BN * LDS_ROW] = reinterpret_cast<short (*)[BN * LDS_ROW]>(smem + 2 * BM * LDS_ROW);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;                 // wave tile: rows wm*32.., cols wn*64..
   const long long m0 = (long long)blockIdx.x * BM;
@@ -101,10 +108,18 @@ __global__ __launch_bounds__(NT) void conv3x3_mfma(const __hip_bfloat16* __restr
   struct Regs { uint4 a[A_L], b[B_L]; unsigned z; };     // z bit i: A row i of this set is zero padding
   Regs S0, S1;
   int f_tap = 0, f_c = 0;                                  // K position of the NEXT fetch (fetches are issued in K order)
+  // Fetches are UNCONDITIONAL, also past the last K step (clamped to the last tap: valid memory, never parked into a buffer that is
+  // read): with `if (s + 3 < ksteps) fetch(...)` the compiler has to assume the path on which the fetch did not happen, on which the
+  // register set about to be parked holds the MOST RECENT loads -- it then waits with vmcnt(3..0), i.e. also for the four loads issued
+  // one step ago, and the two-step prefetch distance silently became one (seen in the ISA; 1 830 cycles per K step and wave).
   auto fetch = [&](Regs& R) {
     uint4 (&a)[A_L] = R.a; uint4 (&bq)[B_L] = R.b; unsigned& z = R.z;
-    const int ky = (f_tap * 11) >> 5, kx = f_tap - ky * 3;  // tap / 3 for tap < 9
-    const int c0 = f_c * BK + sseg * 8;
+    // K order: the nine taps of one 64-channel chunk, then the next chunk -- consecutive steps then read the SAME 128-byte lines of
+    // neighbouring pixels (a tap shifts the tile by one pixel or one row), which the L1 still holds; tap-major order re-read every
+    // line from L2 nine times, and the launch is bound by the CU's L1-miss bandwidth (10 B/cycle with one workgroup per CU, 19 with three)
+    const int tap = f_tap, fc = min(f_c, ksteps_per_tap - 1);
+    const int ky = (tap * 11) >> 5, kx = tap - ky * 3;      // tap / 3 for tap < 9
+    const int c0 = fc * BK + sseg * 8;
     z = 0;
 #pragma unroll
     for (int i = 0; i < A_L; ++i) {
@@ -113,10 +128,10 @@ __global__ __launch_bounds__(NT) void conv3x3_mfma(const __hip_bfloat16* __restr
       if (!ok) { ys = 0; xs = 0; z |= 1u << i; }
       a[i] = *reinterpret_cast<const uint4*>(x + (((long long)pn[i] * g.Hs + ys) * g.Ws + xs) * C + c0);
     }
-    const long long woff = (long long)f_tap * C + f_c * BK;
+    const long long woff = (long long)tap * C + fc * BK;
 #pragma unroll
     for (int i = 0; i < B_L; ++i) bq[i] = *reinterpret_cast<const uint4*>(wp[i] + woff);
-    if (++f_c == ksteps_per_tap) { f_c = 0; ++f_tap; }
+    if (++f_tap == 9) { f_tap = 0; ++f_c; }
   };
   auto park = [&](int buf, const Regs& R) {
     const uint4 (&a)[A_L] = R.a; const uint4 (&bq)[B_L] = R.b; const unsigned z = R.z;
@@ -127,14 +142,27 @@ __global__ __launch_bounds__(NT) void conv3x3_mfma(const __hip_bfloat16* __restr
     for (int i = 0; i < B_L; ++i) *reinterpret_cast<uint4*>(&Bs[buf][(srow + i * ROWS_PER_PASS) * LDS_ROW + sseg * 8]) = bq[i];
   };
 
-  f32x16 acc[NJ];
+  f32x16 acc[NACC];
 #pragma unroll
-  for (int i = 0; i < NJ; ++i)
+  for (int i = 0; i < NACC; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
   const int fr = lane & 31, fh = lane >> 5;                // fragment row / k-half of this lane
   auto compute = [&](int buf) {
+    if constexpr (KSPLIT) {
+      static_assert(BK / 16 == NT / 64, "one 16-wide K slice per wave");
+      const int ko = wave * 16 + fh * 8;
+      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&As[buf][fr * LDS_ROW + ko]);
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&As[buf][(32 + fr) * LDS_ROW + ko]);
+      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(&Bs[buf][fr * LDS_ROW + ko]);
+      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(&Bs[buf][(32 + fr) * LDS_ROW + ko]);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[3], 0, 0, 0);
+      return;
+    }
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
       const bf16x8 a = *reinterpret_cast<const bf16x8*>(&As[buf][(wm * 32 + fr) * LDS_ROW + kk * 16 + fh * 8]);
@@ -145,24 +173,97 @@ __global__ __launch_bounds__(NT) void conv3x3_mfma(const __hip_bfloat16* __restr
       }
     }
   };
-  // step s waits in register set s % 2 and is parked into LDS buffer s % 2; ksteps = 9 * C / BK >= 9
-  static_assert(NSETS == 2, "the k loop below is written for two register sets");
+  // Three register sets rotate (step s waits in set s % 3), two LDS buffers alternate (step s is parked into buffer s % 2);
+  // ksteps = 9 * C / BK is a multiple of 3.  A load has three compute phases to come back: one workgroup alone on a CU measured
+  // 0.65 us per K step with two sets (= half a load's round trip under load), and the layer3 launch has only 2.3 workgroups per CU.
+  static_assert(NSETS == 3, "the k loop below is written for three register sets");
+  Regs S2;
   fetch(S0);
   fetch(S1);
+  fetch(S2);
   park(0, S0);
-  fetch(S0);                                               // step 2
+  fetch(S0);                                               // step 3
   __syncthreads();
   auto step = [&](int s_, Regs& nxt) {                     // nxt holds step s_ + 1
-    if (s_ < ksteps) {
-      if (s_ + 1 < ksteps) park((s_ & 1) ^ 1, nxt);        // that buffer was last read in step s_ - 1 (barrier since)
-      if (s_ + 3 < ksteps) fetch(nxt);                     // step s_ + 3
-      compute(s_ & 1);
-    }
+    park((s_ & 1) ^ 1, nxt);                               // that buffer was last read in step s_ - 1 (barrier since); past the end: unread
+    fetch(nxt);                                            // step s_ + 4 (past the end: a clamped, unused load)
+    if (s_ < ksteps) compute(s_ & 1);
     __syncthreads();
   };
-  for (int ks = 0; ks < ksteps; ks += 2) {
+  for (int ks = 0; ks < ksteps; ks += 3) {
     step(ks, S1);
-    step(ks + 1, S0);
+    step(ks + 1, S2);
+    step(ks + 2, S0);
+  }
+  if constexpr (KSPLIT) {
+    // ---- sum the four waves' partial 64 x 64 tiles through LDS (the K loop ended with a barrier: the staging buffers are free).
+    // A tile image is [MFMA tile t = 2 * (row / 32) + col / 32][register r][lane]: 4096 floats, conflict-free for its writer.
+    float* red = reinterpret_cast<float*>(smem);
+    static_assert(sizeof(smem) >= 2 * 4096 * sizeof(float), "two tile images");
+    auto put = [&](float* d) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[(t * 16 + r) * 64 + lane] = acc[t][r];
+    };
+    auto add = [&](const float* d) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] += d[(t * 16 + r) * 64 + lane];
+    };
+    if (wave >= 2) put(red + (wave - 2) * 4096);
+    __syncthreads();
+    if (wave < 2) add(red + wave * 4096);
+    __syncthreads();
+    if (wave == 1) put(red + 4096);
+    __syncthreads();
+    if (wave == 0) { add(red + 4096); put(red); }
+    __syncthreads();
+    // ---- epilogue by all 256 threads: thread = (tile row m, 16 consecutive columns) -> one 32-byte store
+    const int m = tid >> 2, nq = (tid & 3) * 16;
+    const long long row = m0 + m;
+    if (row < g.M) {
+      const int r = (m & 3) + 4 * ((m & 31) >> 3), h = ((m & 31) >> 2) & 1, t0 = (m >> 5) * 2 + (nq >> 5);
+      const float* src = red + (t0 * 16 + r) * 64 + (nq & 31) + 32 * h;
+      const int col0 = n0 + nq;
+      short o[16];
+      float sc[16], bi[16];
+      const bool full = col0 + 16 <= g.Cout;
+      if (full) {                                                             // 16 consecutive floats each: 4 + 4 vector loads, issued together
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 a = scale ? reinterpret_cast<const float4*>(scale + col0)[q] : make_float4(1.f, 1.f, 1.f, 1.f);
+          const float4 b = bias ? reinterpret_cast<const float4*>(bias + col0)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+          sc[4 * q] = a.x, sc[4 * q + 1] = a.y, sc[4 * q + 2] = a.z, sc[4 * q + 3] = a.w;
+          bi[4 * q] = b.x, bi[4 * q + 1] = b.y, bi[4 * q + 2] = b.z, bi[4 * q + 3] = b.w;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int col = min(col0 + j, g.Cout - 1);
+          sc[j] = scale ? scale[col] : 1.f;
+          bi[j] = bias ? bias[col] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        float v = src[j] * sc[j] + bi[j];                                     // frozen-BN affine / conv bias in the epilogue
+        if (relu) v = fmaxf(v, 0.f);
+        o[j] = (short)__bfloat16_as_ushort(__float2bfloat16(v));
+      }
+      __hip_bfloat16* dst = y + row * g.Cout + col0;
+      if (col0 + 16 <= g.Cout && (g.Cout & 7) == 0) {
+        bf16x8 lo, hi;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { lo[j] = o[j]; hi[j] = o[8 + j]; }
+        *reinterpret_cast<bf16x8*>(dst) = lo;
+        *reinterpret_cast<bf16x8*>(dst + 8) = hi;
+      } else {
+        for (int j = 0; j < 16 && col0 + j < g.Cout; ++j) reinterpret_cast<short*>(dst)[j] = o[j];
+      }
+    }
+    return;
   }
   // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
