@@ -74,6 +74,8 @@ struct State {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   void* cmp_ref = nullptr;            // the reference candidate's whole output (grown on demand)
   size_t cmp_bytes = 0;
+  void* scratch_c = nullptr;          // output stand-in for tuning a plan that accumulates into its C (beta != 0)
+  size_t scratch_bytes = 0;
   unsigned* cmp_out = nullptr;        // [2]: bit patterns of max |c - ref| and max |ref|
   long long tuned_plans = 0, tuned_changed = 0, tuned_rejected = 0;
   std::unordered_map<hipStream_t, void*> workspaces;
@@ -385,8 +387,32 @@ extern "C" int ocpg_gemm(const void* A, const void* B, void* C, const void* bias
            [&](const hipblasLtMatmulAlgo_t& algo, size_t ws) {
              return hipblasLtMatmul(s.handle, p.desc, &alpha, B, p.a, A, p.b, &beta, C, p.c, C, p.c, &algo, workspace, ws, (hipStream_t)stream);
            });
-    else
-      p.tuned = true;           // C += ... cannot be repeated
+    else {
+      // C += ... cannot be repeated on the caller's C: the candidates are timed and compared with beta = 0 on a scratch output of the
+      // same layout (same kernels, same operands), and the winner serves the accumulating calls
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      const size_t span = (size_t)((batch - 1) * (batch > 1 ? strideC : 0) + (M - 1) * ldc + N), bytes = span * (out_dtype == 0 ? 4 : 2);
+      if (p.ncand > 1 && tuning() && hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {
+        if (s.scratch_bytes < bytes) {
+          if (s.scratch_c) (void)hipFree(s.scratch_c);
+          s.scratch_c = nullptr;
+          s.scratch_bytes = 0;
+          if (hipMalloc(&s.scratch_c, bytes) == hipSuccess) s.scratch_bytes = bytes;
+        }
+        if (s.scratch_c) {
+          const float zero = 0.f;
+          void* Cs = s.scratch_c;
+          tune(s, p, (hipStream_t)stream, workspace, Cs, out_dtype, (long long)span, [&](const hipblasLtMatmulAlgo_t& algo, size_t ws) {
+            return hipblasLtMatmul(s.handle, p.desc, &alpha, B, p.a, A, p.b, &zero, Cs, p.c, Cs, p.c, &algo, workspace, ws, (hipStream_t)stream);
+          });
+        } else {
+          (void)hipGetLastError();
+          p.tuned = true;
+        }
+      } else if (cs == hipStreamCaptureStatusNone) {
+        p.tuned = true;
+      }
+    }
   }
   const hipblasStatus_t st = hipblasLtMatmul(s.handle, p.desc, &alpha, B, p.a, A, p.b, &beta, C, p.c, C, p.c, &p.algo, workspace,
                                              p.workspace, (hipStream_t)stream);

@@ -142,6 +142,7 @@ class ResNetBody(nn.Module):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
 
     def forward(self, x):
+        conv_bn_func.reset_skip_tokens()           # pairing of a block's conv1 with its identity skip is per forward
         x = self.bn1(self.conv1(x), relu=True)
         x = F.max_pool2d(x, 3, stride=2, padding=1)
         out = {}

@@ -17,6 +17,23 @@ from ...._lib import check, lib
 _DT = {torch.float32: 0, torch.bfloat16: 1}
 _CL = torch.channels_last
 EPILOGUE = os.environ.get("OCPG_GEMM_EPILOGUE", "1") != "0"     # A/B switch: BN affine / skip / ReLU in the GEMM epilogue
+# A/B switch: the gradient of a bottleneck's identity skip is ADDED BY THE GEMM that computes conv1's input gradient (C = gz W + 1.0 C on
+# the skip gradient's buffer) instead of by autograd's accumulation (one read-read-write pass over the block input per block: 33 per step).
+# conv1's forward leaves a token for its input; the block's last convolution finds it when its `skip` IS that input, its backward parks
+# the skip gradient in the token and returns None for `skip`; conv1's backward (which runs later) accumulates into the parked buffer.
+SKIP_GRAD_IN_GEMM = os.environ.get("OCPG_SKIP_GRAD_IN_GEMM", "1") != "0"
+_SKIP_TOKENS = {}           # data_ptr of a conv1 input -> token; cleared at the start of every backbone forward (reset_skip_tokens)
+
+
+def reset_skip_tokens():
+    _SKIP_TOKENS.clear()
+
+
+def _same_tensor(a, b):
+    if a is None or b is None:          # a token whose backward already ran (left behind by a block that was not an identity block)
+        return False
+    return a is b or (a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.dtype == b.dtype and a.stride() == b.stride()
+                      and a._version == b._version)
 
 
 def _reduce_partials(part, w_is_cast_copy):
@@ -63,6 +80,15 @@ class Conv1x1BNAct(Function):
         from ...amp_cache import is_cast_copy
         ctx.meta = (bool(relu), skip is not None, splits)
         ctx.w_cast = is_cast_copy(w)
+        ctx.give = ctx.take = None
+        if SKIP_GRAD_IN_GEMM:
+            if skip is not None:
+                tok = _SKIP_TOKENS.pop(skip.data_ptr(), None)
+                if tok is not None and _same_tensor(tok["x"], skip) and ctx.needs_input_grad[4]:
+                    ctx.give = tok                     # this node's skip gradient goes to the token, not to autograd
+            elif ctx.needs_input_grad[0]:
+                ctx.take = {"x": x, "g": None}
+                _SKIP_TOKENS[x.data_ptr()] = ctx.take
         return y
 
     @staticmethod
@@ -86,11 +112,23 @@ class Conv1x1BNAct(Function):
         if rc:
             check(rc, "ocpg_bn_act_bwd")
         gx = gw = None
-        if need_x:      # gx[m, c] = gz[m, co] w[co, c]
-            gx = torch.empty((n, c, h, wd), dtype=x.dtype, device=x.device, memory_format=_CL)
-            rc = L.ocpg_gemm(gz.data_ptr(), w.data_ptr(), gx.data_ptr(), None, dt, dt, 0, 0, m, c, co, co, c, c, 1, 0, 0, 0, 1.0, 0.0, st)
+        if ctx.give is not None and need_skip:
+            ctx.give["g"] = gskip                      # parked for conv1's input-gradient GEMM of this block (runs later in this backward)
+            gskip = None
+        parked = None
+        if ctx.take is not None:
+            parked, ctx.take["g"], ctx.take["x"] = ctx.take["g"], None, None
+        if need_x:      # gx[m, c] = gz[m, co] w[co, c] (+ the block's skip gradient, accumulated in place)
+            acc = parked is not None and parked.dtype == x.dtype and parked.shape == x.shape and parked.is_contiguous(memory_format=_CL)
+            gx = parked if acc else torch.empty((n, c, h, wd), dtype=x.dtype, device=x.device, memory_format=_CL)
+            rc = L.ocpg_gemm(gz.data_ptr(), w.data_ptr(), gx.data_ptr(), None, dt, dt, 0, 0, m, c, co, co, c, c, 1, 0, 0, 0, 1.0,
+                             1.0 if acc else 0.0, st)
             if rc:
                 check(rc, "ocpg_gemm")
+            if parked is not None and not acc:
+                gx = gx + parked
+        elif parked is not None:
+            gx = parked
         if need_w:      # gw[co, c] = gz[m, co]^T x[m, c], rows split into `splits` chunks (one strided-batched GEMM + a sum)
             from ...amp_cache import side_wgrad
             with side_wgrad(ctx.w_cast, gz, x) as sw:          # off the critical path: the weight-gradient stream (amp_cache.side_wgrad)
