@@ -915,7 +915,7 @@ inline int launch_bwd_locattn_row(const float* value, const int64_t* shapes, con
 
 extern "C" {
 
-const char* ocpg_hip_version(void) { return "ocpg_hip gfx950 r2"; }
+const char* ocpg_hip_version(void) { return "ocpg_hip gfx950 r3"; }
 
 int ocpg_msda_fwd_f32(const float* value, const int64_t* shapes, const int64_t* level_start, const float* loc, const float* attn,
                       int N, int S, int M, int D, int L, int Lq, int P, float* out, const int64_t* shapes_host, void* stream) {
