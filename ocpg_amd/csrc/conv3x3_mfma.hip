@@ -23,6 +23,7 @@
 #include <cstdlib>
 
 #include "../../include/ocpg_hip.h"
+#include "conv3x3_halo.h"
 
 namespace {
 
@@ -290,6 +291,12 @@ inline bool narrow_tiles(unsigned mtiles, int ncols) {
   return (long long)mtiles * ((ncols + 127) / 128) < 3 * 256;
 }
 
+// A/B switch: stride-1 convolutions through the halo-staged kernel (csrc/conv3x3_halo.hip)
+inline bool halo_variant() {
+  static const bool on = [] { const char* e = std::getenv("OCPG_CONV3X3_HALO"); return e && e[0] == '1'; }();
+  return on;
+}
+
 }  // namespace
 
 // x [N,H,W,Cin] bf16 channels-last, w [Cout,3,3,Cin] bf16 -> y [N,Ho,Wo,Cout] bf16 = act(conv(x, w) * scale + bias); pad 1, stride 1 / 2;
@@ -302,6 +309,12 @@ extern "C" int ocpg_conv3x3_mfma_fwd(const void* x, const void* w, const float* 
   if (!x) return -1001;
   if (!w) return -1002;
   if (!y) return -1010;
+  if (stride == 1 && halo_variant() &&
+      ocpg_halo::conv3x3_halo((const __hip_bfloat16*)x, (const __hip_bfloat16*)w, scale, bias, relu, 0, N, H, W, Cin, Cout, (__hip_bfloat16*)y,
+                              (hipStream_t)stream)) {
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+  }
   ConvGeom g;
   g.N = N; g.H = (H - 1) / stride + 1; g.W = (W - 1) / stride + 1; g.C = Cin; g.Hs = H; g.Ws = W; g.Cout = Cout; g.stride = stride;
   g.M = (long long)N * g.H * g.W;
@@ -325,6 +338,12 @@ extern "C" int ocpg_conv3x3_mfma_dgrad(const void* dy, const void* wT, int N, in
   if (!dy) return -1001;
   if (!wT) return -1002;
   if (!dx) return -1009;
+  if (stride == 1 && halo_variant() &&
+      ocpg_halo::conv3x3_halo((const __hip_bfloat16*)dy, (const __hip_bfloat16*)wT, nullptr, nullptr, 0, 1, N, H, W, Cout, Cin, (__hip_bfloat16*)dx,
+                              (hipStream_t)stream)) {
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+  }
   ConvGeom g;
   g.N = N; g.H = H; g.W = W; g.C = Cout; g.Hs = (H - 1) / stride + 1; g.Ws = (W - 1) / stride + 1; g.Cout = Cin; g.stride = stride;
   g.M = (long long)N * H * W;
