@@ -198,6 +198,8 @@ class SwinTransformerBlock3D(nn.Module):
         self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
         self.norm2 = _lp_norm(norm_layer, dim)
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        if not use_checkpoint:      # every Linear of a block runs once per forward: its gradient sums ride in the fused gradient cast
+            amp_cache.mark_single_use(self.attn.qkv, self.attn.proj, self.mlp.fc1, self.mlp.fc2)
 
     def _plan(self, D, H, W, device):
         ws, ss = get_window_size((D, H, W), self.window_size, self.shift_size)
@@ -249,6 +251,7 @@ class PatchMerging(nn.Module):
         super().__init__()
         self.dim = dim
         self.reduction = amp_cache.Linear(4 * dim, 2 * dim, bias=False)
+        amp_cache.mark_single_use(self.reduction)
         self.norm = _lp_norm(norm_layer, 4 * dim)
 
     def forward(self, x):
