@@ -4,7 +4,7 @@
 // Here one pass each way: x in fp32 or bf16, statistics and arithmetic in fp32, y written in the dtype the next Linear consumes.
 //   fwd: y = (x - mean) * rstd * gamma + beta;  mean / rstd [rows] fp32 kept for the backward
 //   bwd: dx = rstd * (g gamma - mean_c(g gamma) - xhat * mean_c(g gamma xhat));  dgamma / dbeta through per-workgroup partial rows
-// One wave per row, C <= 1024 (16 elements per lane); HBM-bound.
+// One wave per row (2 / 4 / 8 / 16 contiguous channels per lane, vector loads, up to four rows in flight), C <= 1024; HBM-bound.
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
@@ -33,79 +33,193 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// ---- a lane's contiguous chunk of E elements (c = lane * E .. + E - 1): vector loads / stores in the storage type ----------------
+template <int E> __device__ __forceinline__ void ld_chunk(const void* p, int code, long long i, float (&v)[E]) {
+  if (code == 1) {
+    const float* q = reinterpret_cast<const float*>(p) + i;
+    if constexpr (E >= 4) {
+#pragma unroll
+      for (int k = 0; k < E / 4; ++k) {
+        const float4 t = reinterpret_cast<const float4*>(q)[k];
+        v[4 * k] = t.x, v[4 * k + 1] = t.y, v[4 * k + 2] = t.z, v[4 * k + 3] = t.w;
+      }
+    } else {
+      const float2 t = *reinterpret_cast<const float2*>(q);
+      v[0] = t.x, v[1] = t.y;
+    }
+    return;
+  }
+  const unsigned short* q = reinterpret_cast<const unsigned short*>(p) + i;
+  unsigned w[E / 2];
+  if constexpr (E >= 8) {
+#pragma unroll
+    for (int k = 0; k < E / 8; ++k) {
+      const uint4 t = reinterpret_cast<const uint4*>(q)[k];
+      w[4 * k] = t.x, w[4 * k + 1] = t.y, w[4 * k + 2] = t.z, w[4 * k + 3] = t.w;
+    }
+  } else if constexpr (E == 4) {
+    const uint2 t = *reinterpret_cast<const uint2*>(q);
+    w[0] = t.x, w[1] = t.y;
+  } else {
+    w[0] = *reinterpret_cast<const unsigned*>(q);
+  }
+#pragma unroll
+  for (int k = 0; k < E / 2; ++k) {
+    const unsigned short lo = (unsigned short)(w[k] & 0xffffu), hi = (unsigned short)(w[k] >> 16);
+    if (code == 2) {
+      v[2 * k] = __half2float(__ushort_as_half(lo));
+      v[2 * k + 1] = __half2float(__ushort_as_half(hi));
+    } else {
+      v[2 * k] = __uint_as_float((unsigned)lo << 16);
+      v[2 * k + 1] = __uint_as_float((unsigned)hi << 16);
+    }
+  }
+}
+
+template <int E> __device__ __forceinline__ void st_chunk(void* p, int code, long long i, const float (&v)[E]) {
+  if (code == 1) {
+    float* q = reinterpret_cast<float*>(p) + i;
+    if constexpr (E >= 4) {
+#pragma unroll
+      for (int k = 0; k < E / 4; ++k) reinterpret_cast<float4*>(q)[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+    } else {
+      *reinterpret_cast<float2*>(q) = make_float2(v[0], v[1]);
+    }
+    return;
+  }
+  unsigned w[E / 2];
+#pragma unroll
+  for (int k = 0; k < E / 2; ++k) {
+    unsigned short lo, hi;
+    if (code == 2) {
+      lo = __half_as_ushort(__float2half(v[2 * k]));
+      hi = __half_as_ushort(__float2half(v[2 * k + 1]));
+    } else {
+      lo = __bfloat16_as_ushort(__float2bfloat16(v[2 * k]));
+      hi = __bfloat16_as_ushort(__float2bfloat16(v[2 * k + 1]));
+    }
+    w[k] = (unsigned)lo | ((unsigned)hi << 16);
+  }
+  unsigned short* q = reinterpret_cast<unsigned short*>(p) + i;
+  if constexpr (E >= 8) {
+#pragma unroll
+    for (int k = 0; k < E / 8; ++k) reinterpret_cast<uint4*>(q)[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+  } else if constexpr (E == 4) {
+    *reinterpret_cast<uint2*>(q) = make_uint2(w[0], w[1]);
+  } else {
+    *reinterpret_cast<unsigned*>(q) = w[0];
+  }
+}
+
+// One wave per row, a lane owns the E consecutive channels lane * E .. (C % E == 0, C <= 64 E), R rows in flight per wave: all loads of
+// the R rows are issued before the first reduction (a wave that took one row at a time with 2-byte loads ran at 0.9 TB/s on the
+// [102 720, 128] fp16 maps of Swin-B's first stage: each row was a load -> 12 shuffles -> store latency chain).
+template <int E, int R>
 __global__ __launch_bounds__(NT) void ln_fwd(const void* __restrict__ x, int x_f32, const float* __restrict__ gamma, const float* __restrict__ beta,
                                              long long rows, int C, float eps, void* __restrict__ y, int y_f32, float* __restrict__ mean,
                                              float* __restrict__ rstd) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (long long row = (long long)blockIdx.x * (NT / 64) + wave; row < rows; row += (long long)gridDim.x * (NT / 64)) {
-    float v[MAXE];
-    float s = 0.f;
+  const int c0 = lane * E;
+  const bool act = c0 < C;
+  float gm[E], bt[E];
 #pragma unroll
-    for (int e = 0; e < MAXE; ++e) {
-      const int c = lane + 64 * e;
-      v[e] = c < C ? ldv(x, x_f32, row * C + c) : 0.f;
-      s += v[e];
-    }
-    const float mu = wave_sum(s) / (float)C;
-    float q = 0.f;
+  for (int e = 0; e < E; ++e) { gm[e] = act ? gamma[c0 + e] : 0.f; bt[e] = act ? beta[c0 + e] : 0.f; }
+  const float inv = 1.f / (float)C;
+  for (long long rb = ((long long)blockIdx.x * (NT / 64) + wave) * R; rb < rows; rb += (long long)gridDim.x * (NT / 64) * R) {
+    float v[R][E];
 #pragma unroll
-    for (int e = 0; e < MAXE; ++e) {
-      const int c = lane + 64 * e;
-      const float d = c < C ? v[e] - mu : 0.f;
-      q += d * d;
-    }
-    const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
+    for (int r = 0; r < R; ++r) {
+      const long long row = rb + r < rows ? rb + r : rows - 1;
+      if (act) ld_chunk<E>(x, x_f32, row * C + c0, v[r]);
+      else
 #pragma unroll
-    for (int e = 0; e < MAXE; ++e) {
-      const int c = lane + 64 * e;
-      if (c < C) stv(y, y_f32, row * C + c, (v[e] - mu) * rs * gamma[c] + beta[c]);
+        for (int e = 0; e < E; ++e) v[r][e] = 0.f;
     }
-    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < E; ++e) s += v[r][e];
+      const float mu = wave_sum(s) * inv;
+      float q = 0.f;
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const float d = act ? v[r][e] - mu : 0.f;
+        q += d * d;
+      }
+      const float rs = rsqrtf(wave_sum(q) * inv + eps);
+      if (rb + r < rows) {
+        if (act) {
+          float o[E];
+#pragma unroll
+          for (int e = 0; e < E; ++e) o[e] = (v[r][e] - mu) * rs * gm[e] + bt[e];
+          st_chunk<E>(y, y_f32, (rb + r) * C + c0, o);
+        }
+        if (lane == 0) { mean[rb + r] = mu; rstd[rb + r] = rs; }
+      }
+    }
   }
 }
 
 // part_g / part_b [gridDim.x, C]: per-workgroup partial sums of dgamma / dbeta
+template <int E, int R>
 __global__ __launch_bounds__(NT) void ln_bwd(const void* __restrict__ gy, int gy_f32, const void* __restrict__ x, int x_f32,
                                              const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
                                              long long rows, int C, void* __restrict__ dx, int dx_f32, float* __restrict__ part_g,
                                              float* __restrict__ part_b) {
-  __shared__ float red[2][NT / 64][64 * MAXE];      // 2 x 4 x 1024 floats = 32 KB
+  __shared__ float red[2][NT / 64][64 * E];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float ag[MAXE], ab[MAXE], gm[MAXE];
+  const int c0 = lane * E;
+  const bool act = c0 < C;
+  float ag[E], ab[E], gm[E];
 #pragma unroll
-  for (int e = 0; e < MAXE; ++e) {
+  for (int e = 0; e < E; ++e) {
     ag[e] = 0.f; ab[e] = 0.f;
-    const int c = lane + 64 * e;
-    gm[e] = c < C ? gamma[c] : 0.f;
+    gm[e] = act ? gamma[c0 + e] : 0.f;
   }
-  for (long long row = (long long)blockIdx.x * (NT / 64) + wave; row < rows; row += (long long)gridDim.x * (NT / 64)) {
-    const float mu = mean[row], rs = rstd[row];
-    float g[MAXE], xh[MAXE];
-    float s1 = 0.f, s2 = 0.f;
+  const float inv = 1.f / (float)C;
+  for (long long rb = ((long long)blockIdx.x * (NT / 64) + wave) * R; rb < rows; rb += (long long)gridDim.x * (NT / 64) * R) {
+    float g[R][E], xh[R][E], mu[R], rs[R];
 #pragma unroll
-    for (int e = 0; e < MAXE; ++e) {
-      const int c = lane + 64 * e;
-      const bool ok = c < C;
-      g[e] = ok ? ldv(gy, gy_f32, row * C + c) : 0.f;
-      xh[e] = ok ? (ldv(x, x_f32, row * C + c) - mu) * rs : 0.f;
-      const float gg = g[e] * gm[e];
-      s1 += gg;
-      s2 += gg * xh[e];
-      ag[e] += g[e] * xh[e];
-      ab[e] += g[e];
+    for (int r = 0; r < R; ++r) {
+      const bool ok = rb + r < rows;
+      const long long row = ok ? rb + r : rows - 1;
+      mu[r] = mean[row];
+      rs[r] = rstd[row];
+      if (act && ok) {
+        ld_chunk<E>(gy, gy_f32, row * C + c0, g[r]);
+        ld_chunk<E>(x, x_f32, row * C + c0, xh[r]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) { g[r][e] = 0.f; xh[r][e] = mu[r]; }
+      }
     }
-    s1 = wave_sum(s1) / (float)C;
-    s2 = wave_sum(s2) / (float)C;
 #pragma unroll
-    for (int e = 0; e < MAXE; ++e) {
-      const int c = lane + 64 * e;
-      if (c < C) stv(dx, dx_f32, row * C + c, rs * (g[e] * gm[e] - s1 - xh[e] * s2));
+    for (int r = 0; r < R; ++r) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        xh[r][e] = (xh[r][e] - mu[r]) * rs[r];
+        const float gg = g[r][e] * gm[e];
+        s1 += gg;
+        s2 += gg * xh[r][e];
+        ag[e] += g[r][e] * xh[r][e];
+        ab[e] += g[r][e];
+      }
+      s1 = wave_sum(s1) * inv;
+      s2 = wave_sum(s2) * inv;
+      if (act && rb + r < rows) {
+        float o[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) o[e] = rs[r] * (g[r][e] * gm[e] - s1 - xh[r][e] * s2);
+        st_chunk<E>(dx, dx_f32, (rb + r) * C + c0, o);
+      }
     }
   }
 #pragma unroll
-  for (int e = 0; e < MAXE; ++e) {
-    red[0][wave][lane + 64 * e] = ag[e];
-    red[1][wave][lane + 64 * e] = ab[e];
+  for (int e = 0; e < E; ++e) {
+    red[0][wave][c0 + e] = ag[e];
+    red[1][wave][c0 + e] = ab[e];
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += NT) {
@@ -115,6 +229,13 @@ __global__ __launch_bounds__(NT) void ln_bwd(const void* __restrict__ gy, int gy
     part_g[(long long)blockIdx.x * C + c] = sg;
     part_b[(long long)blockIdx.x * C + c] = sb;
   }
+}
+
+// elements per lane for C channels: the smallest of 2 / 4 / 8 / 16 with 64 E >= C and C % E == 0 (0: not served)
+inline int chunk_for(int C) {
+  for (int e = 2; e <= MAXE; e *= 2)
+    if (64 * e >= C && C % e == 0) return e;
+  return 0;
 }
 
 inline int status() {
@@ -134,21 +255,33 @@ int ocpg_layernorm_blocks(long long rows) {
 int ocpg_layernorm_fwd(const void* x, int x_f32, const float* gamma, const float* beta, long long rows, int C, float eps, void* y, int y_f32,
                        float* mean, float* rstd, void* stream) {
   if (rows < 0 || C <= 0) return -1005;
-  if (C > 64 * MAXE) return -2000;
+  const int e = chunk_for(C);
+  if (C > 64 * MAXE || !e) return -2000;
   if (rows == 0) return 0;
   if (!x || !gamma || !beta) return -1001;
   if (!y || !mean || !rstd) return -1008;
-  ln_fwd<<<ocpg_layernorm_blocks(rows), NT, 0, (hipStream_t)stream>>>(x, x_f32, gamma, beta, rows, C, eps, y, y_f32, mean, rstd);
+  const unsigned nb = (unsigned)ocpg_layernorm_blocks(rows);
+  hipStream_t st = (hipStream_t)stream;
+  if (e == 2) ln_fwd<2, 4><<<nb, NT, 0, st>>>(x, x_f32, gamma, beta, rows, C, eps, y, y_f32, mean, rstd);
+  else if (e == 4) ln_fwd<4, 4><<<nb, NT, 0, st>>>(x, x_f32, gamma, beta, rows, C, eps, y, y_f32, mean, rstd);
+  else if (e == 8) ln_fwd<8, 2><<<nb, NT, 0, st>>>(x, x_f32, gamma, beta, rows, C, eps, y, y_f32, mean, rstd);
+  else ln_fwd<16, 1><<<nb, NT, 0, st>>>(x, x_f32, gamma, beta, rows, C, eps, y, y_f32, mean, rstd);
   return status();
 }
 
 int ocpg_layernorm_bwd(const void* gy, int gy_f32, const void* x, int x_f32, const float* gamma, const float* mean, const float* rstd,
                        long long rows, int C, void* dx, int dx_f32, float* part_g, float* part_b, void* stream) {
   if (rows <= 0 || C <= 0) return -1008;
-  if (C > 64 * MAXE) return -2000;
+  const int e = chunk_for(C);
+  if (C > 64 * MAXE || !e) return -2000;
   if (!gy || !x || !gamma || !mean || !rstd) return -1001;
   if (!dx || !part_g || !part_b) return -1010;
-  ln_bwd<<<ocpg_layernorm_blocks(rows), NT, 0, (hipStream_t)stream>>>(gy, gy_f32, x, x_f32, gamma, mean, rstd, rows, C, dx, dx_f32, part_g, part_b);
+  const unsigned nb = (unsigned)ocpg_layernorm_blocks(rows);
+  hipStream_t st = (hipStream_t)stream;
+  if (e == 2) ln_bwd<2, 4><<<nb, NT, 0, st>>>(gy, gy_f32, x, x_f32, gamma, mean, rstd, rows, C, dx, dx_f32, part_g, part_b);
+  else if (e == 4) ln_bwd<4, 4><<<nb, NT, 0, st>>>(gy, gy_f32, x, x_f32, gamma, mean, rstd, rows, C, dx, dx_f32, part_g, part_b);
+  else if (e == 8) ln_bwd<8, 2><<<nb, NT, 0, st>>>(gy, gy_f32, x, x_f32, gamma, mean, rstd, rows, C, dx, dx_f32, part_g, part_b);
+  else ln_bwd<16, 1><<<nb, NT, 0, st>>>(gy, gy_f32, x, x_f32, gamma, mean, rstd, rows, C, dx, dx_f32, part_g, part_b);
   return status();
 }
 
