@@ -47,7 +47,7 @@ class DropPath(nn.Module):
             return x
         keep = 1.0 - self.drop_prob
         mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
-        return x * mask / keep
+        return x * mask.div_(keep)          # timm scales the [B, 1, ...] mask, then one multiply over the map
 
 
 class Mlp(nn.Module):

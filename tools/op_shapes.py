@@ -11,7 +11,7 @@ import bench
 from ocpg_amd.models import build_model
 
 dev = torch.device("cuda:0")
-args = bench.model_args(dev, "resnet101", amp=True)
+args = bench.model_args(dev, os.environ.get("BACKBONE", "resnet101"), amp=True)
 model, crit, _ = build_model(args)
 model.to(dev), crit.to(dev)
 for m in model.modules():
