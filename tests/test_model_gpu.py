@@ -1264,3 +1264,23 @@ def test_clip_adamw_kernels_equal_torch(dev):
     assert all(float(v["step"]) == 4.0 for v in sd["state"].values())
     plain = torch.optim.AdamW(groups([torch.nn.Parameter(p.detach().clone(memory_format=torch.preserve_format)) for p in a]), lr=1e-2, weight_decay=5e-4)
     plain.load_state_dict(sd)                 # interchangeable with torch's optimizer (checkpoint wire format, row f2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(9600, 256), (51000, 384), (777, 100), (40000, 2048), (130, 96), (5, 8)])
+def test_colsum_partials_equals_sum(dev, dtype, shape):
+    """ocpg_colsum_partials (16-byte loads, (vector column, row phase) threads, LDS fold; scalar path when C is not a whole number of
+    vectors): the partial rows add up to the fp64 column sums of the matrix as stored."""
+    from ocpg_amd._lib import check, lib
+    r, c = shape
+    g = torch.Generator().manual_seed(r + c)
+    x = torch.randn(r, c, generator=g).to(dtype).to(dev)
+    code = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[dtype]
+    nb = int(lib().ocpg_colsum_blocks(r))
+    assert 1 <= nb <= 256
+    part = torch.full((nb, c), float("nan"), dtype=torch.float32, device=dev)
+    check(lib().ocpg_colsum_partials(x.data_ptr(), r, c, code, part.data_ptr(), torch.cuda.current_stream().cuda_stream), "ocpg_colsum_partials")
+    want = x.double().sum(0)
+    got = part.double().sum(0)
+    assert torch.isfinite(part).all()
+    assert (got - want).abs().max().item() <= 1e-5 * (x.double().abs().sum(0).max().item() + 1.0)
