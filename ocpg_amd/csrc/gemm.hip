@@ -195,10 +195,11 @@ Plan build(State& s, const Key& key) {
   // hipBLASLt's hand-written "Custom_Cijk_..._MT256x256x64" kernels returned intermittently WRONG rows on a [8200 x 64] x [64 x 1032]
   // bf16 product (K = one depth-64 iteration; tools/dbg_brd_after_mso.py with OCPG_GEMM_TUNE_LOG=1: the same kernel agrees with the
   // default in one run and is off by the size of the values in the next): never a candidate below four K iterations
-  auto unsafe = [&](hipblasLtMatmulAlgo_t a) {
-    return key.k < 256 && hipblaslt_ext::getKernelNameFromAlgo(s.handle, a).rfind("Custom_", 0) == 0;
-  };
-  const bool default_unsafe = unsafe(p.algo);
+  // ... and at any K never a candidate the heuristic did not put FIRST itself (a kernel that is wrong one run in many passes any
+  // finite number of checks; as hipBLASLt's own first choice it is what every other caller of the library runs too)
+  auto custom = [&](hipblasLtMatmulAlgo_t a) { return hipblaslt_ext::getKernelNameFromAlgo(s.handle, a).rfind("Custom_", 0) == 0; };
+  auto unsafe = [&](hipblasLtMatmulAlgo_t a) { return custom(a); };
+  const bool default_unsafe = key.k < 256 && custom(p.algo);
   if ((tuning() && (key.dtype != 0 || tuning_fp32())) || default_unsafe) {
     found = 0;
     st = hipblasLtMatmulAlgoGetHeuristic(s.handle, p.desc, p.a, p.b, p.c, p.c, pref, kCandidates - 1, res, &found);

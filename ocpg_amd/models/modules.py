@@ -11,7 +11,7 @@ from torch import nn
 
 from ..util.misc import memo
 from . import amp_cache
-from .ops.functions.spectral_func import conv3x3_valid_spatial_mean, pair_to_complex, spectral_gate, spectral_gate_cl
+from .ops.functions.spectral_func import conv3x3_valid_spatial_mean, ifft2_real, pair_to_complex, spectral_gate, spectral_gate_cl
 
 FUSED_GATE = True       # A/B switch: fused spectral gate kernel
 GATE_NHWC = True        # A/B switch: gate output / inverse-FFT input in channels-last memory (1x1 convs as GEMMs, no casts / layout copies)
@@ -69,7 +69,7 @@ class LFMResizeAdaptive(nn.Module):
             dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
             z = spectral_gate_cl(torch.fft.fft2(x), coef.float().reshape(b), high.reshape(h, w), dt)
             y = self.conv2(F.relu(self.conv1(z)))                   # channels-last in, channels-last out: two GEMMs
-            y = torch.fft.ifft2(pair_to_complex(y), s=(h, w)).real.float()
+            y = ifft2_real(pair_to_complex(y), h, w)              # = torch.fft.ifft2(..., s=(h, w)).real, real-to-complex backward
             return x + y, high
         if x.is_cuda and FUSED_GATE:
             # gate, real/imag split and concatenation in one pass (csrc/spectral.hip)

@@ -137,3 +137,27 @@ def spectral_gate_cl(spec, coef, high, dtype):
 
 def pair_to_complex(y):
     return PairToComplex.apply(y)
+
+
+class IFFT2Real(Function):
+    """ifft2(z, s=(h, w)).real of a complex spectrum (models/modules.py:53-54) as one node.  autograd's backward of `.real` first builds
+    a complex tensor (zeros + strided copy of the gradient: two passes over a [2560, 48, 80] complex map at the finest level) and runs
+    a complex-to-complex transform on it; the gradient is REAL, so the same result is the real-to-complex transform
+    fft2(g, norm="forward") -- half the butterflies and no complex staging."""
+
+    @staticmethod
+    def forward(ctx, z, h, w):
+        ctx.sizes = (tuple(z.shape[-2:]), (h, w))
+        return torch.fft.ifft2(z, s=(h, w)).real
+
+    @staticmethod
+    def backward(ctx, g):
+        (zh, zw), (h, w) = ctx.sizes
+        gz = torch.fft.fft2(g if g.dtype == torch.float32 else g.float(), norm="forward")
+        if (zh, zw) != (h, w):          # ifft2 cropped / zero-padded its input to s: the mirror image on the way back
+            gz = torch.nn.functional.pad(gz[..., :min(zh, h), :min(zw, w)], (0, max(zw - w, 0), 0, max(zh - h, 0)))
+        return gz, None, None
+
+
+def ifft2_real(z, h, w):
+    return IFFT2Real.apply(z, int(h), int(w))
