@@ -519,6 +519,11 @@ LIB_WORK = {
     "ocpg_mso_conv3x3": ("hbm", lambda a: a[13] * a[14] * a[15] * (a[16] * _esz(a[1]) + a[17] * (_esz(a[12]) + (_esz(a[9]) if a[8] else 0)
                                                                   + (4 if a[10] else 0))) + (a[7] * a[14] * a[15] * a[17] * 4 if a[6] else 0)),
     "ocpg_mso_wgrad": ("hbm", lambda a: a[7] * a[8] * a[9] * (a[10] * _esz(a[1]) + a[11] * 4)),
+    "ocpg_colsum_partials": ("hbm", lambda a: a[1] * a[2] * _esz(a[3])),
+    "ocpg_im2col3x3_nhwc": ("hbm", lambda a: _esz(a[8]) * a[4] * a[1] * (a[2] * a[3] + 9 * ((a[2] - 1) // a[5] + 1) * ((a[3] - 1) // a[5] + 1))),
+    # optimizer: 2048-element chunks (the last chunk of a tensor is partial: an upper bound); p, g, m, v read, p, m, v written / g read
+    "ocpg_adamw_step": ("hbm", lambda a: a[9] * 2048 * 28),
+    "ocpg_grad_norm_clip": ("hbm", lambda a: a[4] * 2048 * 4),
     "ocpg_dynmask_fwd_f32": ("valu", lambda a: a[3] * a[4] * a[6] * a[7] * (2 * 16 * (a[5] + 2) + 2 * 16 * 16)),
     "ocpg_dynmask_bwd_f32": ("valu", lambda a: 2 * a[3] * a[4] * a[6] * a[7] * (2 * 16 * (a[5] + 2) + 2 * 16 * 16)),
     # matrix-core kernels: FLOPs = 2 * M * N * K (* batch); bf16 / fp16 storage -> the 2.5 PF peak, fp32 GEMMs -> the 157 TF fp32 peak
