@@ -530,6 +530,7 @@ LIB_WORK = {
     "ocpg_gemm": ("mfma", lambda a: 2.0 * a[8] * a[9] * a[10] * max(a[14], 1), lambda a: a[4] != 0),
     "ocpg_gemm_bn_act": ("mfma", lambda a: 2.0 * a[8] * a[9] * a[10], lambda a: a[7] != 0),
     "ocpg_conv3x3_mfma_fwd": ("mfma", lambda a: 2.0 * a[5] * ((a[6] - 1) // a[10] + 1) * ((a[7] - 1) // a[10] + 1) * 9 * a[8] * a[9], lambda a: True),
+    "ocpg_conv3x3_mfma_fwd_cols": ("mfma", lambda a: 2.0 * a[5] * ((a[6] - 1) // a[10] + 1) * ((a[7] - 1) // a[10] + 1) * 9 * a[8] * a[9], lambda a: True),
     "ocpg_conv3x3_mfma_dgrad": ("mfma", lambda a: 2.0 * a[2] * ((a[3] - 1) // a[7] + 1) * ((a[4] - 1) // a[7] + 1) * 9 * a[5] * a[6], lambda a: True),
     "ocpg_small_linear_fwd": ("mfma", lambda a: 2.0 * a[4] * a[5] * a[6], lambda a: True),
     "ocpg_small_linear_bwd": ("mfma", lambda a: 4.0 * a[6] * a[7] * a[8], lambda a: True),

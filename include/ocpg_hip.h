@@ -161,6 +161,10 @@ int ocpg_col2im3x3_nhwc(const void* dcols, int N, int H, int W, int C, int strid
  * (ocpg_im2col3x3_nhwc + ocpg_gemm). */
 int ocpg_conv3x3_mfma_fwd(const void* x, const void* w, const float* scale, const float* bias, int relu, int N, int H, int W,
                           int Cin, int Cout, int stride, void* y, void* stream);
+/* the same, and the patch (im2col) matrix of x written on the way: cols [N*Ho*Wo, 9*Cin] bf16 in (ky, kx, ci) column order (what
+ * ocpg_im2col3x3_nhwc produces), or NULL -- the weight gradient of the convolution contracts the output gradient with it. */
+int ocpg_conv3x3_mfma_fwd_cols(const void* x, const void* w, const float* scale, const float* bias, int relu, int N, int H, int W, int Cin,
+                               int Cout, int stride, void* y, void* cols, void* stream);
 int ocpg_conv3x3_mfma_dgrad(const void* dy, const void* wT, int N, int H, int W, int Cin, int Cout, int stride, void* dx,
                             void* stream);
 

@@ -30,6 +30,7 @@ SIGNATURES = {
     "ocpg_dynmask_bwd_pre_f32": [_vp, _vp, _vp] + [_int] * 6 + [_vp, _vp, _vp, _vp],
     "ocpg_dynmask_bwd_fin_f32": [_vp, _vp, _vp, _vp] + [_int] * 5 + [_vp, _vp, _vp],
     "ocpg_conv3x3_mfma_fwd": [_vp, _vp, _vp, _vp] + [_int] * 7 + [_vp, _vp],
+    "ocpg_conv3x3_mfma_fwd_cols": [_vp, _vp, _vp, _vp] + [_int] * 7 + [_vp, _vp, _vp],
     "ocpg_conv3x3_mfma_dgrad": [_vp, _vp] + [_int] * 6 + [_vp, _vp],
     "ocpg_gemm": [_vp, _vp, _vp, _vp] + [_int] * 4 + [ctypes.c_longlong] * 10 + [ctypes.c_float, ctypes.c_float, _vp],
     "ocpg_gemm_plans": [],

@@ -64,7 +64,7 @@ __device__ __forceinline__ bool tap_source(const ConvGeom& g, int y, int x, int 
 template <bool DGRAD, int BN>
 __global__ __launch_bounds__(NT) void conv3x3_mfma(const __hip_bfloat16* __restrict__ x, const __hip_bfloat16* __restrict__ w,
                                                    const float* __restrict__ scale, const float* __restrict__ bias, int relu, ConvGeom g,
-                                                   __hip_bfloat16* __restrict__ y) {
+                                                   __hip_bfloat16* __restrict__ y, __hip_bfloat16* __restrict__ cols) {
   constexpr int B_L = BN / ROWS_PER_PASS, NJ = BN / 64, WN = BN / 2;      // a wave's tile: 32 rows x WN columns = NJ MFMA tiles
   // 64-column tiles: the four waves split the K STEP instead of the tile (wave w takes the 16-wide slice w of every 64-wide step and
   // accumulates the whole 64 x 64 tile = 2 x 2 MFMA tiles): two A and two B fragments feed four MFMAs, where a 32 x 32 wave tile reads
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(NT) void conv3x3_mfma(const __hip_bfloat16* __restr
   // (not a fraction of one) to come back -- at ~1 workgroup per CU (300 workgroups for ResNet-101's layer3 shape) nothing
   // else hides it.  Loads are unconditional (clamped address, zeroed at park time): a load inside a branch gets its own
   // s_waitcnt and serialises the batch.
-  struct Regs { uint4 a[A_L], b[B_L]; unsigned z; };     // z bit i: A row i of this set is zero padding
+  struct Regs { uint4 a[A_L], b[B_L]; unsigned z; int coff; };     // z bit i: A row i of this set is zero padding; coff: its column in the patch matrix (-1: past the end)
   Regs S0, S1;
   int f_tap = 0, f_c = 0;                                  // K position of the NEXT fetch (fetches are issued in K order)
   // Fetches are UNCONDITIONAL, also past the last K step (clamped to the last tap: valid memory, never parked into a buffer that is
@@ -121,6 +121,7 @@ __global__ __launch_bounds__(NT) void conv3x3_mfma(const __hip_bfloat16* __restr
     const int tap = f_tap, fc = min(f_c, ksteps_per_tap - 1);
     const int ky = (tap * 11) >> 5, kx = tap - ky * 3;      // tap / 3 for tap < 9
     const int c0 = fc * BK + sseg * 8;
+    R.coff = f_c < ksteps_per_tap ? tap * C + c0 : -1;
     z = 0;
 #pragma unroll
     for (int i = 0; i < A_L; ++i) {
@@ -141,6 +142,16 @@ __global__ __launch_bounds__(NT) void conv3x3_mfma(const __hip_bfloat16* __restr
       *reinterpret_cast<uint4*>(&As[buf][(srow + i * ROWS_PER_PASS) * LDS_ROW + sseg * 8]) = ((z >> i) & 1u) ? make_uint4(0u, 0u, 0u, 0u) : a[i];
 #pragma unroll
     for (int i = 0; i < B_L; ++i) *reinterpret_cast<uint4*>(&Bs[buf][(srow + i * ROWS_PER_PASS) * LDS_ROW + sseg * 8]) = bq[i];
+    if constexpr (!DGRAD) {
+      // the gathered A tiles ARE the rows of the patch (im2col) matrix the weight gradient contracts with: the column-0 workgroups
+      // write them out on the way (16 bytes per thread and row) and the backward needs no im2col pass
+      if (cols && blockIdx.y == 0 && R.coff >= 0) {
+#pragma unroll
+        for (int i = 0; i < A_L; ++i)
+          if (row_ok[i])
+            *reinterpret_cast<uint4*>(cols + (m0 + srow + i * ROWS_PER_PASS) * (9LL * C) + R.coff) = ((z >> i) & 1u) ? make_uint4(0u, 0u, 0u, 0u) : a[i];
+      }
+    }
   };
 
   f32x16 acc[NACC];
@@ -301,15 +312,16 @@ inline bool halo_variant() {
 
 // x [N,H,W,Cin] bf16 channels-last, w [Cout,3,3,Cin] bf16 -> y [N,Ho,Wo,Cout] bf16 = act(conv(x, w) * scale + bias); pad 1, stride 1 / 2;
 // scale / bias fp32 [Cout] or NULL (1 / 0): the frozen-BN affine of the ResNet body, or a plain conv bias
-extern "C" int ocpg_conv3x3_mfma_fwd(const void* x, const void* w, const float* scale, const float* bias, int relu, int N, int H, int W,
-                                     int Cin, int Cout, int stride, void* y, void* stream) {
+// cols (may be NULL): [N*Ho*Wo, 9*Cin] bf16, the patch matrix of x in (ky, kx, ci) order = what ocpg_im2col3x3_nhwc would write
+extern "C" int ocpg_conv3x3_mfma_fwd_cols(const void* x, const void* w, const float* scale, const float* bias, int relu, int N, int H, int W,
+                                          int Cin, int Cout, int stride, void* y, void* cols, void* stream) {
   if (N < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return -1006;
   if ((stride != 1 && stride != 2) || Cin % BK != 0) return -2000;
   if (N == 0) return 0;
   if (!x) return -1001;
   if (!w) return -1002;
   if (!y) return -1010;
-  if (stride == 1 && halo_variant() &&
+  if (stride == 1 && !cols && halo_variant() &&
       ocpg_halo::conv3x3_halo((const __hip_bfloat16*)x, (const __hip_bfloat16*)w, scale, bias, relu, 0, N, H, W, Cin, Cout, (__hip_bfloat16*)y,
                               (hipStream_t)stream)) {
     const hipError_t e = hipGetLastError();
@@ -321,12 +333,17 @@ extern "C" int ocpg_conv3x3_mfma_fwd(const void* x, const void* w, const float* 
   const unsigned mt = (unsigned)((g.M + BM - 1) / BM);
   if (narrow_tiles(mt, Cout))
     conv3x3_mfma<false, 64><<<dim3(mt, (unsigned)((Cout + 63) / 64)), NT, 0, (hipStream_t)stream>>>(
-        (const __hip_bfloat16*)x, (const __hip_bfloat16*)w, scale, bias, relu, g, (__hip_bfloat16*)y);
+        (const __hip_bfloat16*)x, (const __hip_bfloat16*)w, scale, bias, relu, g, (__hip_bfloat16*)y, (__hip_bfloat16*)cols);
   else
     conv3x3_mfma<false, 128><<<dim3(mt, (unsigned)((Cout + 127) / 128)), NT, 0, (hipStream_t)stream>>>(
-        (const __hip_bfloat16*)x, (const __hip_bfloat16*)w, scale, bias, relu, g, (__hip_bfloat16*)y);
+        (const __hip_bfloat16*)x, (const __hip_bfloat16*)w, scale, bias, relu, g, (__hip_bfloat16*)y, (__hip_bfloat16*)cols);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
+}
+
+extern "C" int ocpg_conv3x3_mfma_fwd(const void* x, const void* w, const float* scale, const float* bias, int relu, int N, int H, int W,
+                                     int Cin, int Cout, int stride, void* y, void* stream) {
+  return ocpg_conv3x3_mfma_fwd_cols(x, w, scale, bias, relu, N, H, W, Cin, Cout, stride, y, nullptr, stream);
 }
 
 // dy [N,Ho,Wo,Cout] bf16, wT [Cin,3,3,Cout] bf16 (the weight with its channel axes swapped) -> dx [N,H,W,Cin] bf16 fully written
@@ -350,10 +367,10 @@ extern "C" int ocpg_conv3x3_mfma_dgrad(const void* dy, const void* wT, int N, in
   const unsigned mt = (unsigned)((g.M + BM - 1) / BM);
   if (narrow_tiles(mt, Cin))
     conv3x3_mfma<true, 64><<<dim3(mt, (unsigned)((Cin + 63) / 64)), NT, 0, (hipStream_t)stream>>>(
-        (const __hip_bfloat16*)dy, (const __hip_bfloat16*)wT, nullptr, nullptr, 0, g, (__hip_bfloat16*)dx);
+        (const __hip_bfloat16*)dy, (const __hip_bfloat16*)wT, nullptr, nullptr, 0, g, (__hip_bfloat16*)dx, nullptr);
   else
     conv3x3_mfma<true, 128><<<dim3(mt, (unsigned)((Cin + 127) / 128)), NT, 0, (hipStream_t)stream>>>(
-        (const __hip_bfloat16*)dy, (const __hip_bfloat16*)wT, nullptr, nullptr, 0, g, (__hip_bfloat16*)dx);
+        (const __hip_bfloat16*)dy, (const __hip_bfloat16*)wT, nullptr, nullptr, 0, g, (__hip_bfloat16*)dx, nullptr);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }

@@ -21,6 +21,9 @@ EPILOGUE = os.environ.get("OCPG_GEMM_EPILOGUE", "1") != "0"     # A/B switch: BN
 # the skip gradient's buffer) instead of by autograd's accumulation (one read-read-write pass over the block input per block: 33 per step).
 # conv1's forward leaves a token for its input; the block's last convolution finds it when its `skip` IS that input, its backward parks
 # the skip gradient in the token and returns None for `skip`; conv1's backward (which runs later) accumulates into the parked buffer.
+# A/B switch (default off: measured neutral, 38.8-39.2 vs 39.0 ms): conv3x3_mfma's forward also writes the patch matrix its weight gradient
+# contracts with, instead of an im2col launch in the backward (the extra stores cost the forward what the launch cost the backward)
+FWD_COLS = os.environ.get("OCPG_CONV3X3_FWD_COLS", "0") != "0"
 SKIP_GRAD_IN_GEMM = os.environ.get("OCPG_SKIP_GRAD_IN_GEMM", "1") != "0"
 _SKIP_TOKENS = {}           # data_ptr of a conv1 input -> token; cleared at the start of every backbone forward (reset_skip_tokens)
 
@@ -261,9 +264,16 @@ class Conv3x3MfmaBNAct(Function):
             w2 = w2.contiguous()
         y = torch.empty((n, co, ho, wo), dtype=x.dtype, device=x.device, memory_format=_CL)
         st = torch.cuda.current_stream().cuda_stream
-        check(lib().ocpg_conv3x3_mfma_fwd(x.data_ptr(), w2.data_ptr(), scale.data_ptr(), shift.data_ptr(), int(relu), n, h, wd, c, co, stride,
-                                          y.data_ptr(), st), "ocpg_conv3x3_mfma_fwd")
-        ctx.save_for_backward(x, w2, y, scale)
+        # the forward kernel gathers exactly the rows of the patch matrix the weight gradient needs: kept (44 MB per layer3 conv, 1.4 GB over
+        # the ResNet-101 body at 10 frames) instead of re-gathered by an im2col launch in the backward
+        cols = torch.empty((n * ho * wo, 9 * c), dtype=x.dtype, device=x.device) if (FWD_COLS and ctx.needs_input_grad[1]) else None
+        check(lib().ocpg_conv3x3_mfma_fwd_cols(x.data_ptr(), w2.data_ptr(), scale.data_ptr(), shift.data_ptr(), int(relu), n, h, wd, c, co, stride,
+                                               y.data_ptr(), None if cols is None else cols.data_ptr(), st), "ocpg_conv3x3_mfma_fwd_cols")
+        ctx.has_cols = cols is not None
+        if cols is not None:
+            ctx.save_for_backward(x, w2, y, scale, cols)
+        else:
+            ctx.save_for_backward(x, w2, y, scale)
         from ...amp_cache import is_cast_copy
         ctx.meta = (bool(relu), splits, stride)
         ctx.w_cast = is_cast_copy(w)
@@ -272,7 +282,7 @@ class Conv3x3MfmaBNAct(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        x, w2, y, scale = ctx.saved_tensors
+        x, w2, y, scale = ctx.saved_tensors[:4]
         relu, splits, stride = ctx.meta
         n, c, h, wd = x.shape
         co, ho, wo = y.shape[1], y.shape[2], y.shape[3]
@@ -292,8 +302,11 @@ class Conv3x3MfmaBNAct(Function):
             from ...amp_cache import side_wgrad
             with side_wgrad(ctx.w_cast, gz, x) as sw:          # off the critical path: the weight-gradient stream (amp_cache.side_wgrad)
                 st = torch.cuda.current_stream().cuda_stream
-                cols = torch.empty((m, k), dtype=y.dtype, device=y.device)
-                check(L.ocpg_im2col3x3_nhwc(x.data_ptr(), n, h, wd, c, stride, 1, cols.data_ptr(), 1, st), "ocpg_im2col3x3_nhwc")
+                if ctx.has_cols:
+                    cols = ctx.saved_tensors[4]
+                else:
+                    cols = torch.empty((m, k), dtype=y.dtype, device=y.device)
+                    check(L.ocpg_im2col3x3_nhwc(x.data_ptr(), n, h, wd, c, stride, 1, cols.data_ptr(), 1, st), "ocpg_im2col3x3_nhwc")
                 if splits > 1 and m % splits == 0:
                     r = m // splits
                     part = torch.empty((splits, co, k), dtype=y.dtype, device=y.device)
