@@ -68,11 +68,31 @@ def build(force=False, verbose=False):
     if todo:
         with ThreadPoolExecutor(max_workers=min(8, len(todo))) as ex:
             list(ex.map(one, todo))
-    if todo or not os.path.exists(LIB):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + objs + LINK
+    # the link has its own stamp: the sorted object list with each object's stamp + the link line.  A renamed / deleted source, a
+    # link that failed after the objects were written, or a library older than its objects all relink.
+    for stale in glob.glob(os.path.join(OBJDIR, "*.o")):
+        if stale not in objs:                   # object of a source that no longer exists
+            os.remove(stale)
+            if os.path.exists(stale + ".stamp"):
+                os.remove(stale + ".stamp")
+    link_cmd = [HIPCC, "--offload-arch=gfx950", "-fPIC", "-shared"] + EXTRA + ["-o", LIB] + objs + LINK
+    lh = hashlib.sha1(" ".join(link_cmd).encode())
+    for o in objs:
+        lh.update(open(o + ".stamp").read().encode())
+    lstamp, lfile = lh.hexdigest(), LIB + ".stamp"
+    try:
+        linked = (os.path.exists(LIB) and open(lfile).read() == lstamp
+                  and os.path.getmtime(LIB) >= max(os.path.getmtime(o) for o in objs))
+    except OSError:
+        linked = False
+    if force or todo or not linked:
         if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+            print(" ".join(link_cmd), flush=True)
+        if os.path.exists(lfile):
+            os.remove(lfile)
+        subprocess.check_call(link_cmd)
+        with open(lfile, "w") as f:
+            f.write(lstamp)
     return LIB
 
 

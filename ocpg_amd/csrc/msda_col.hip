@@ -724,6 +724,7 @@ __global__ __launch_bounds__(NT) void k_scatter_col2(const float* __restrict__ l
         const int pl = pp - (u ? wpx0 : 0), ww = tc.ww[l];
         const int dy = (int)udiv(pl, ww, tc.m_ww[l]);
         const int gpix = tc.S0[l] + (tc.wy0[l] + dy) * tc.W[l] + tc.wx0[l] + pl - dy * ww;      // pixel of this group in the whole map
+#ifndef EXP_NO_FLUSH
         {
           const float send1 = odd ? acc.x : acc.y, send2 = odd ? acc.z : acc.w;
           const float got1 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send1), 0x128, 0xF, 0xF, true));   // row_ror:8 = lane ^ 8
@@ -742,6 +743,9 @@ __global__ __launch_bounds__(NT) void k_scatter_col2(const float* __restrict__ l
             atomicAdd(g + 2 * G, odd ? acc.w : got2);
           }
         }
+#else
+        if (valid && acc.x + acc.y + acc.z + acc.w == 1.2345f) gvb[gpix] = acc.x;     // timing-only build: keeps the sums alive, never stores
+#endif
         if (valid && j == 0) cnt[pp] = 0;        // ready for the next pass
       }
       lds_barrier();

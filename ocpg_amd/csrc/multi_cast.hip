@@ -53,8 +53,6 @@ __global__ __launch_bounds__(256) void multi_cast_sum(const long long* __restric
     __shared__ float accs[CHUNK];
     const long long cb = (blk - chunk_prefix[lo]) * CHUNK;
     const int cnt = (int)(count - cb < CHUNK ? count - cb : CHUNK);
-    for (int i = threadIdx.x; i < cnt; i += 256) accs[i] = 0.f;
-    __syncthreads();
     int groups = CHUNK / cnt;                 // slices are dealt round-robin to the groups
     if (groups > ns) groups = (int)ns;
     for (int w = threadIdx.x; w < cnt * groups; w += 256) {
@@ -68,10 +66,14 @@ __global__ __launch_bounds__(256) void multi_cast_sum(const long long* __restric
         a3 += sf[(k + 3LL * groups) * stride + cb + e];
       }
       for (; k < ns; k += groups) a0 += sf[k * stride + cb + e];
-      atomicAdd(&accs[e], (a0 + a1) + (a2 + a3));
+      accs[w] = (a0 + a1) + (a2 + a3);        // slot (group, element): w = gk * cnt + e < CHUNK
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < cnt; i += 256) d[cb + i] = from_f<D>(accs[i]);
+    for (int i = threadIdx.x; i < cnt; i += 256) {        // the groups are folded in a FIXED order: bit-reproducible run to run
+      float t = 0.f;
+      for (int g = 0; g < groups; ++g) t += accs[g * cnt + i];
+      d[cb + i] = from_f<D>(t);
+    }
     return;
   }
   if (base >= count) return;

@@ -136,6 +136,24 @@ def colsum(gy2, like):
     return gy2.sum(0)
 
 
+def _finish_partials(g):
+    """g as it arrived in FusedCast.backward; when it is slice 0 of a deferred partial sum (defer_sum), the sum over all slices."""
+    pr = _PARTIALS.pop(g.data_ptr(), None) if _PARTIALS else None
+    if pr is None:
+        return g
+    splits, stride, numel = pr[0] & ((1 << 40) - 1), pr[1], pr[2]
+    dt = torch.float32 if pr[0] >> 40 else g.dtype            # flagged: fp32 partials behind a low-precision view of slice 0
+    esz = torch.empty((), dtype=dt).element_size()
+    part = torch.empty(0, dtype=dt, device=g.device).set_(g.untyped_storage(), g.storage_offset() * g.element_size() // esz,
+                                                          (splits, numel), (stride, 1))
+    if g.is_contiguous():
+        return part.sum(0).view(g.shape)
+    # slice 0 keeps the memory order of the layout the layer computed it in (dense, e.g. channels-last): sum in that order
+    out = torch.empty_like(g, dtype=dt)
+    out.as_strided((numel,), (1,), out.storage_offset()).copy_(part.sum(0))
+    return out
+
+
 def is_cast_copy(w):
     """True for the low-precision working copy FusedCast made of a parameter (its gradient is first read by FusedCast.backward)."""
     return w.grad_fn is not None and w.grad_fn.name() == "FusedCastBackward"
@@ -301,7 +319,9 @@ class FusedCast(torch.autograd.Function):
                 # gradients take the PARAMETER's strides (DDP's gradient-as-bucket-view layout contract: a channels-last
                 # 1x1 weight [Co,Ci,1,1] and its dense gradient share the memory order but not the nominal strides)
                 outs = [torch.empty_strided(grads[i].shape, ctx.src_strides[i], dtype=ctx.src_dtype, device=grads[i].device) for i in slow]
-                torch._foreach_copy_(outs, [grads[i] for i in slow])
+                # a deferred partial sum that arrives HERE (its layout does not match the plan's, e.g. a weight that is not
+                # channels-last under channels-last activations) is finished now: slice 0 alone would be 1/splits of the gradient
+                torch._foreach_copy_(outs, [_finish_partials(grads[i]) for i in slow])
                 for i, o in zip(slow, outs):
                     res[i] = o
         return (None, None, *res)

@@ -53,6 +53,9 @@ class MSO(nn.Module):
         if self.mask_dim > 16 or self.mask_dim % 4 or pm.dtype not in _FLOATS or f4.dtype not in _FLOATS or f8.dtype not in _FLOATS:
             fallbacks.note("MSO", f"mask_dim {self.mask_dim} / dtypes {pm.dtype}, {f4.dtype}, {f8.dtype} not served by csrc/mso.hip", pm)
             return False
+        if pm.shape[0] > 65535:        # the kernels put the image index on a 16-bit grid axis (ocpg_mso_conv3x3 returns -1002 beyond it)
+            fallbacks.note("MSO", f"{pm.shape[0]} mask maps in one call exceed the kernel's grid axis", pm)
+            return False
         return True
 
     def forward_native(self, pm, f4, f8):

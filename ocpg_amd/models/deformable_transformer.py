@@ -48,7 +48,16 @@ def _ffn_hidden(src, linear1, activation, drop):
 
 
 def _clones(module, n):
-    return nn.ModuleList([copy.deepcopy(module) for _ in range(n)])
+    """n deep copies (deformable_transformer.py:401-402).  Parameter.__deepcopy__ drops instance attributes, so the single-use marks
+    (amp_cache.mark_single_use: deferred weight-gradient sums) are carried over to the copies' parameters by hand."""
+    out = []
+    for _ in range(n):
+        c = copy.deepcopy(module)
+        for p, q in zip(module.parameters(), c.parameters()):
+            if getattr(p, "_ocpg_single_use", False):
+                q._ocpg_single_use = True
+        out.append(c)
+    return nn.ModuleList(out)
 
 
 def _activation(name):

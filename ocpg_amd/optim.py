@@ -34,6 +34,13 @@ class ClipAdamW(torch.optim.AdamW):
         return g.dtype == torch.float32 and g.device == p.device and tuple(g.shape) == tuple(p.shape) and \
             all(a == b or n == 1 for a, b, n in zip(g.stride(), p.stride(), p.shape))
 
+    def _key(self, ent):
+        """Every address the kernels write through: a re-assigned p.data / .grad / moment (memory-format or device moves, a DDP
+        rebuild, load_state_dict) must rebuild the tables -- a stale table would be a write into freed memory."""
+        st = self.state
+        return tuple((p.data_ptr(), p.grad.data_ptr(), st[p]["exp_avg"].data_ptr() if len(st[p]) else 0,
+                      st[p]["exp_avg_sq"].data_ptr() if len(st[p]) else 0) for p, _ in ent)
+
     def _build(self, ent):
         dev = ent[0][0].device
         for p, _ in ent:
@@ -49,10 +56,11 @@ class ClipAdamW(torch.optim.AdamW):
         for n in numels:
             prefix.append(prefix[-1] + (n + _CHUNK - 1) // _CHUNK)
         t = {"n": len(ent), "chunks": prefix[-1], "params": [p for p, _ in ent], "groups": [gi for _, gi in ent],
-             "key": tuple(p.grad.data_ptr() for p, _ in ent),
+             "key": self._key(ent),
+             # (through pinned memory: a pageable upload would stall the host until the stream drains)
              "meta": torch.tensor([[p.data_ptr() for p, _ in ent], [p.grad.data_ptr() for p, _ in ent],
                                    [self.state[p]["exp_avg"].data_ptr() for p, _ in ent], [self.state[p]["exp_avg_sq"].data_ptr() for p, _ in ent],
-                                   numels, prefix[:-1]], dtype=torch.int64).to(dev),
+                                   numels, prefix[:-1]], dtype=torch.int64).pin_memory().to(dev, non_blocking=True),
              "partials": torch.empty(max(prefix[-1], 1), dtype=torch.float32, device=dev),
              "norm": torch.zeros(2, dtype=torch.float32, device=dev), "hyper_key": None, "hyper": None}
         return t
@@ -77,7 +85,7 @@ class ClipAdamW(torch.optim.AdamW):
             if not self._dense_like(p.grad, p):    # (does not happen on this path: gradients are born with their parameter's strides)
                 p.grad = torch.empty_like(p).copy_(p.grad)
         t = self._tables
-        if t is None or t["key"] != tuple(p.grad.data_ptr() for p, _ in ent) or t["params"] != [p for p, _ in ent]:
+        if t is None or len(t["params"]) != len(ent) or any(a is not b for a, (b, _) in zip(t["params"], ent)) or t["key"] != self._key(ent):
             t = self._tables = self._build(ent)
         hyper = self._hyper(t)
         g0 = self.param_groups[0]
@@ -106,9 +114,12 @@ class ClipAdamW(torch.optim.AdamW):
         return loss
 
     def _sync_steps(self):
-        if self._steps:
-            for st in self.state.values():
-                if "step" in st:
+        """state[p]["step"] of the parameters the kernels step (the tables' members) = the count the kernels were given; parameters
+        that never received a gradient keep their own (torch.optim.AdamW does not step them either)."""
+        if self._steps and self._tables is not None:
+            for p in self._tables["params"]:
+                st = self.state.get(p)
+                if st is not None and "step" in st:
                     st["step"] = torch.tensor(float(self._steps))
 
     def state_dict(self):

@@ -170,3 +170,30 @@ def test_gemm_helpers_and_groupnorm_take_the_tensor_path_off_gpu():
     m = torch.randn(2, 32, 5, 6).contiguous(memory_format=torch.channels_last)
     assert not eligible(m, gn)
     assert torch.equal(gn(m), ref(m))
+
+
+def test_deferred_partials_are_finished_on_the_slow_cast_path():
+    """amp_cache.defer_sum hands slice 0 of a row-split weight gradient to autograd and leaves the other slices to the fused gradient
+    cast.  A gradient whose layout does not match the cast plan takes FusedCast.backward's per-tensor path: it must finish the sum
+    there (slice 0 alone is 1 / splits of the gradient) and consume the registry entry."""
+    from ocpg_amd.models import amp_cache
+    torch.manual_seed(0)
+    amp_cache._PARTIALS.clear()
+    part = torch.randn(5, 4, 6)
+    g = amp_cache.defer_sum(part)
+    assert g.data_ptr() in amp_cache._PARTIALS
+    assert torch.allclose(amp_cache._finish_partials(g), part.sum(0), atol=1e-6) and not amp_cache._PARTIALS
+    # a dense, permuted view of slice 0 (a 3x3 weight gradient computed in channels-last order)
+    part = torch.randn(3, 8, 3, 3, 4)                          # [S, Co, ky, kx, Ci]
+    g = amp_cache.defer_sum(part).permute(0, 3, 1, 2)          # [Co, Ci, ky, kx] with channels-last strides
+    out = amp_cache._finish_partials(g)
+    assert out.stride() == g.stride() and torch.allclose(out, part.sum(0).permute(0, 3, 1, 2), atol=1e-6) and not amp_cache._PARTIALS
+    # fp32 partials behind a low-precision view of slice 0 (bias column sums)
+    part = torch.randn(7, 16)
+    g = amp_cache.defer_sum(part, torch.bfloat16)
+    assert g.dtype == torch.bfloat16 and g.shape == (16,)
+    out = amp_cache._finish_partials(g)
+    assert out.dtype == torch.float32 and torch.allclose(out, part.sum(0), atol=1e-6) and not amp_cache._PARTIALS
+    # nothing registered: the gradient passes through untouched
+    t = torch.randn(3, 3)
+    assert amp_cache._finish_partials(t) is t

@@ -64,17 +64,22 @@ algo = 4 * N * (S * M * D + S * M * D + 3 * S * M * L * P)        # read loc, at
 g = torch.Generator().manual_seed(1)
 attn = torch.softmax(torch.randn(N, S, M, L * P, generator=g), -1).view(N, S, M, L, P).to(dev)
 go = torch.randn(N, S, M * D, generator=g).to(dev)
+MODES = os.environ.get("GV_MODES", "ring,ring+n,trained").split(",")
+PATHS = os.environ.get("GV_PATHS", "1,0").split(",")
 for mode, (noise, outl) in (("ring", (0.0, 0.0)), ("ring+n", (1.5, 0.02)), ("trained", (3.0, 0.05))):
+    if mode not in MODES:
+        continue
     loc = ring_loc(noise, outl).to(dev)
     res = {}
-    for tile in ("1", "0"):
+    for tile in PATHS:
         os.environ["OCPG_MSDA_TILE"] = tile
         gv = torch.zeros(N, S, M, D, device=dev)
         us = run(loc, attn, go, gv, int(os.environ.get("ITERS", "30")))
         res[tile] = gv
         print(json.dumps({"mode": mode, "path": "tile" if tile == "1" else "column", "n_frames": N, "us": round(us, 1),
                           "algorithmic_bytes": algo, "GBs": round(algo / us / 1e3, 1), "frac_of_8TBs": round(algo / us / 1e3 / 8000, 4)}), flush=True)
-    d = (res["1"] - res["0"]).abs().max().item() / res["0"].abs().max().item()
-    print(json.dumps({"mode": mode, "tile_vs_column_max_rel": d}), flush=True)
-    assert d < 3e-5, d
+    if len(res) == 2 and os.environ.get("GV_NOCHECK") != "1":
+        d = (res["1"] - res["0"]).abs().max().item() / res["0"].abs().max().item()
+        print(json.dumps({"mode": mode, "tile_vs_column_max_rel": d}), flush=True)
+        assert d < 3e-5, d
 os.environ.pop("OCPG_MSDA_TILE", None)
