@@ -875,7 +875,8 @@ inline int launch_bwd_value_col(const float* loc, const float* attn, const float
   if (te && te[0] == '1' && ocpg_tile::bwd_value_tile(loc, attn, grad_out, shapes_host, N, S, M, D, L, P, grad_value, st)) return 1;
   ocpg_col::ColGeom cg;
   const char* tw = std::getenv("OCPG_MSDA_TILEW");      // experiment switch: scatter tile width on the finest level
-  if (!ocpg_col::make_col_geom(shapes_host, L, S, M, P, 8, tw ? std::atoi(tw) : 16, cg)) return 0;
+  static const int mlo = [] { const char* e = std::getenv("OCPG_MSDA_MARGIN_LO"); return e ? std::atoi(e) : ocpg_col::kScatterMarginLo; }();    // A/B
+  if (!ocpg_col::make_col_geom(shapes_host, L, S, M, P, 8, tw ? std::atoi(tw) : 16, cg, mlo, ocpg_col::kMarginHi)) return 0;
   return ocpg_col::bwd_scatter_col(loc, attn, grad_out, N, S, M, D, P, cg, grad_value, st);
 }
 

@@ -6,8 +6,12 @@
 namespace ocpg_col {
 
 constexpr int kMaxLevels = 4;
-constexpr int kMarginLo = 4;   // window extends this many pixels below the tile's footprint ...
+constexpr int kMarginLo = 4;   // gather kernels: window extends this many pixels below the tile's footprint ...
 constexpr int kMarginHi = 5;   // ... and this many above (x0 + 1 is the far corner)
+// Scatter kernels (round 4): 5 below.  At the model's initial ring offsets (<= 4 pixels) a query of a FINER level lands a quarter to
+// three quarters of a pixel below its column's footprint at a coarser level, so with 4 below 1.07 % of the samples missed the window --
+// and each miss is a wave-serial step with four global atomics: 30 of the kernel's 190 us (measured by cutting the kernel, tools/r4_exp7.sh).
+constexpr int kScatterMarginLo = 5;
 
 // Host-derived tiling of one (frame, head) problem into "pyramid columns": the finest level is cut into
 // nty x ntx blocks of <= 8x8 pixels; a column owns, at EVERY level, the pixels whose index range scales to the same
@@ -17,6 +21,7 @@ constexpr int kMarginHi = 5;   // ... and this many above (x0 + 1 is the far cor
 struct ColGeom {
   int L, nty, ntx, ntiles;
   unsigned m_ntx, m_nty, m_ntiles, m_M, m_P;   // multiply-high reciprocals (no integer divide on the device)
+  int mlo, mhi;   // window margins below / above the footprint, in pixels of the destination level
   int tmax;   // max queries of a column
   int wmax;   // max window pixels of a (column, level)
   int wrest;  // max window pixels of a column over levels 1..L-1
@@ -25,7 +30,8 @@ struct ColGeom {
 
 // false: shapes not supported by the column kernels (caller falls back to the row kernels)
 // tile_h x tile_w: block of the finest level that defines a column (8x8 for the gather kernels, 8x16 for the scatter)
-bool make_col_geom(const int64_t* shapes_host, int L, int S, int M, int P, int tile_h, int tile_w, ColGeom& g);
+bool make_col_geom(const int64_t* shapes_host, int L, int S, int M, int P, int tile_h, int tile_w, ColGeom& g, int margin_lo = kMarginLo,
+                   int margin_hi = kMarginHi);
 
 bool scatter_supported(const ColGeom& g, int D, int P);
 

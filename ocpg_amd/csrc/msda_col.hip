@@ -90,11 +90,11 @@ __device__ __forceinline__ void tile_setup(const ColGeom& geo, int tile, TileCtx
     t.m_cw[l] = magic_of(cx1 - cx0);
     t.nq[l] = (ry1 - ry0) * (cx1 - cx0);
     const int fy1 = max(ry1, ry0 + 1), fx1 = max(cx1, cx0 + 1);     // footprint even when the column has no query here
-    const int wy0 = max(0, ry0 - kMarginLo), wx0 = max(0, cx0 - kMarginLo);
+    const int wy0 = max(0, ry0 - geo.mlo), wx0 = max(0, cx0 - geo.mlo);
     t.wy0[l] = wy0;
     t.wx0[l] = wx0;
-    t.wh[l] = min(H, fy1 + kMarginHi) - wy0;
-    t.ww[l] = min(W, fx1 + kMarginHi) - wx0;
+    t.wh[l] = min(H, fy1 + geo.mhi) - wy0;
+    t.ww[l] = min(W, fx1 + geo.mhi) - wx0;
     t.m_ww[l] = magic_of(t.ww[l]);
   }
   __syncthreads();
@@ -753,6 +753,744 @@ __global__ __launch_bounds__(NT) void k_scatter_col2(const float* __restrict__ l
   }
 }
 
+// ----------------------------------------------------------------------------------------------------------------------
+// Backward-scatter, ALL destination levels in ONE pass (round 4).  Measured on the level-pair kernel above (a build without the
+// flush atomics, tools/r4_exp1.sh): 179 us with or without them -- the kernel is bound by its own phase structure, not by the
+// memory-side atomic rate: two passes x five barriers, one LDS atomic + one list entry per CORNER, and a final phase in which the few
+// coarse-level pixels (136 / 340 contributions each at levels 2 / 3 against 11 at level 0) keep a quarter of the lane groups busy.
+// Here:
+//   * the unit that is sorted is the SAMPLE, not the corner: one counter atomic and one 16-byte item {lx, ly, a, row} per sample,
+//     binned by its top-left pixel on a (wh + 1) x (ww + 1) grid per level (row / column -1 of the window included); a pixel then
+//     walks the lists of the four bins that can hold a sample touching it and forms the corner weight on the fly (3 multiplies);
+//   * all levels are binned together (965 bins at config #2): one bin phase, one scan, one item phase, one sum phase -- 5 barriers;
+//   * the sum phase is a TASK list built from the counts: a pixel with few contributions is one lane group's task, a heavy pixel
+//     (coarse levels) is a whole wave's -- its 8 lane groups stride over the lists and add their partial sums through three
+//     cross-lane exchanges -- so every lane group carries about the same number of contributions.
+// Same results as the kernels above up to the order of the fp32 sums.
+#ifdef EXP_STAMPS
+#define S3_INIT unsigned tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tprev3 = __builtin_amdgcn_s_memtime()
+#define S3(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc_[(k) & 7] += (unsigned)(t_ - tprev3); tprev3 = t_; } while (0)
+#define S3_FLUSH do { if (tid == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_stamps[8 + i_], (unsigned long long)tacc_[i_]); } } while (0)
+#else
+#define S3_INIT do { } while (0)
+#define S3(k) do { } while (0)
+#define S3_FLUSH do { } while (0)
+#endif
+
+struct __attribute__((aligned(16))) SItem {
+  float lx, ly, a;
+  int q;        // float offset of the query's staged grad_out row
+};
+
+constexpr int kBins3 = 1280;       // sum over levels of (wh + 1) * (ww + 1) at most (1 070 at config #2 with 5 + 5 margins)
+constexpr int kHeavy = 48;         // contributions from which a pixel becomes a whole wave's task
+
+template <int NT>
+__global__ __launch_bounds__(NT, 6) void k_scatter_col3(const float* __restrict__ loc, const float* __restrict__ attn,
+                                                         const float* __restrict__ gout, int S, int M, int P, ColGeom geo,
+                                                         float* __restrict__ gvalue) {
+  constexpr int G = 8, D = 32, GROUPS = NT / G, NW = NT / 64, BPL = kBins3 / 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* gs = reinterpret_cast<float*>(smem);                                             // [tmax][D], channel j + G*c at 4*j + c
+  SItem* items = reinterpret_cast<SItem*>(smem + (size_t)geo.tmax * D * sizeof(float));    // [L * tmax * P]
+  int* qg = reinterpret_cast<int*>(items + (size_t)geo.L * geo.tmax * P);                  // [tmax]
+  __shared__ int cnt[kBins3], start[kBins3 + 1];
+  __shared__ unsigned short task_n[kBins3], task_w[256];
+  __shared__ int boff[kLM + 1], n_narrow, n_wide;
+  __shared__ TileCtx tc;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bid = blockIdx.x;
+  const int bt = (int)udiv(bid, M, geo.m_M);
+  const int m = bid - bt * M;
+  const int b = (int)udiv(bt, geo.ntiles, geo.m_ntiles), tile = bt - b * geo.ntiles;
+  S3_INIT;
+  for (int i = tid; i < kBins3; i += NT) cnt[i] = 0;
+  if (tid == 0) { n_narrow = 0; n_wide = 0; }
+  tile_setup(geo, tile, tc, tid);
+  const int L = geo.L, NS = L * P, MD = M * D;
+  const int T = tc.qbase[L], TP = T * P;
+  if (tid <= L) {
+    int o = 0;
+    for (int k = 0; k < tid; ++k) o += (tc.wh[k] + 1) * (tc.ww[k] + 1);
+    boff[tid] = o;
+  }
+  for (int i = tid; i < T; i += NT) qg[i] = local_to_query(tc, L, i);
+  __syncthreads();
+  S3(0);
+  const int j = tid % G;
+  const int ts = min(tid, TP - 1);
+  const int qloc = (int)udiv(ts, P, geo.m_P);
+  float2 sxy[kLM];
+  float sa[kLM];
+  {
+    const int p = ts - qloc * P;
+    const long long wi0 = (((long long)b * S + qg[qloc]) * M + m) * NS + p;
+#pragma unroll
+    for (int l = 0; l < kLM; ++l) {
+      const long long wi = wi0 + min(l, L - 1) * P;
+      sxy[l] = *reinterpret_cast<const float2*>(loc + wi * 2);
+      sa[l] = attn[wi];
+    }
+  }
+  {
+    float4 gq[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int ql = min(tid / G + u * GROUPS, T - 1);
+      const float* g = gout + (((long long)b * S + qg[ql]) * M + m) * D + j;
+      gq[u] = make_float4(g[0], g[G], g[2 * G], g[3 * G]);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int ql = tid / G + u * GROUPS;
+      if (ql < T) *reinterpret_cast<float4*>(gs + ql * D + 4 * j) = gq[u];
+    }
+  }
+  float* gvb = gvalue + (long long)b * S * MD + m * D;
+  // (1) bin this thread's sample of every level by its top-left pixel.  bin >= 0: inside the window; bin = -1 - mask: outside (mask = its
+  // corners inside the map, 0 = no sample), and `slot` then holds the corner-0 pixel of the direct path instead of a list slot
+  int bin[kLM], slot[kLM];
+  float slx[kLM], sly[kLM];
+#pragma unroll
+  for (int l = 0; l < kLM; ++l) {
+    bin[l] = -1; slot[l] = 0; slx[l] = 0.f; sly[l] = 0.f;
+    if (l < L && tid < TP) {
+      const int H = tc.H[l], W = tc.W[l], wy0 = tc.wy0[l], wx0 = tc.wx0[l], wh = tc.wh[l], ww = tc.ww[l];
+      const float h_im = sxy[l].y * (float)H - 0.5f, w_im = sxy[l].x * (float)W - 0.5f;
+      if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+        const int y0 = (int)floorf(h_im), x0 = (int)floorf(w_im);
+        sly[l] = h_im - (float)y0; slx[l] = w_im - (float)x0;
+        const bool in = max(y0, 0) >= wy0 && min(y0 + 1, H - 1) < wy0 + wh && max(x0, 0) >= wx0 && min(x0 + 1, W - 1) < wx0 + ww;
+        if (in) {
+          bin[l] = boff[l] + (y0 - wy0 + 1) * (ww + 1) + (x0 - wx0 + 1);
+        } else {
+          const bool y0ok = y0 >= 0, y1ok = y0 + 1 <= H - 1, x0ok = x0 >= 0, x1ok = x0 + 1 <= W - 1;
+          bin[l] = -1 - ((y0ok && x0ok ? 1 : 0) | (y0ok && x1ok ? 2 : 0) | (y1ok && x0ok ? 4 : 0) | (y1ok && x1ok ? 8 : 0));
+          slot[l] = y0 * W + x0;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int l = 0; l < kLM; ++l)
+    if (bin[l] >= 0) slot[l] = atomicAdd(&cnt[bin[l]], 1);
+  __syncthreads();           // gs staged (the direct path below reads it), counts complete
+  S3(1);
+#pragma unroll
+  for (int l = 0; l < kLM; ++l) {
+    if (l < L) {
+      // samples outside the window: straight to memory, one sample per wave step, D lanes x 4 B contiguous per corner
+      const int W = tc.W[l];
+      float* gvl = gvb + (long long)tc.S0[l] * MD;
+      unsigned long long bal = __ballot(bin[l] < -1);
+      while (bal) {
+        const int src = __ffsll((long long)bal) - 1;
+        bal &= bal - 1;
+        const int om = -1 - __builtin_amdgcn_readlane(bin[l], src), gp = __builtin_amdgcn_readlane(slot[l], src),
+                  qs = __builtin_amdgcn_readlane(qloc, src);
+        const float lx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(slx[l]), src));
+        const float ly = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sly[l]), src));
+        const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sa[l]), src));
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        if (lane < D) {
+          const float g = gs[qs * D + 4 * (lane % G) + lane / G];
+          if (om & 1) atomicAdd(gvl + (long long)gp * MD + lane, hy * hx * a * g);
+          if (om & 2) atomicAdd(gvl + (long long)(gp + 1) * MD + lane, hy * lx * a * g);
+          if (om & 4) atomicAdd(gvl + (long long)(gp + W) * MD + lane, ly * hx * a * g);
+          if (om & 8) atomicAdd(gvl + (long long)(gp + W + 1) * MD + lane, ly * lx * a * g);
+        }
+      }
+    }
+  }
+#if defined(EXP_COL3_CUT) && EXP_COL3_CUT == 1
+  if (slot[0] == 12345678) gvb[0] = slx[0] + sly[1] + sa[2] + gs[tid];
+  return;
+#endif
+  // (2) wave 0: list starts of all bins; the other waves: the task lists (a pixel's contributions = the counts of its four bins)
+  S3(2);
+  const int npix = tc.woff[L];
+  if (wave == 0) {
+    int c[BPL], s = 0;
+#pragma unroll
+    for (int i = 0; i < BPL; ++i) { c[i] = cnt[lane * BPL + i]; s += c[i]; }
+    int inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    int run = inc - s;
+#pragma unroll
+    for (int i = 0; i < BPL; ++i) { start[lane * BPL + i] = run; run += c[i]; }
+    if (lane == 63) start[kBins3] = run;
+  } else {
+    for (int p0 = 0; p0 < npix; p0 += NT - 64) {
+      const int pix = p0 + tid - 64;
+      int work = 0;
+      if (pix < npix) {
+        int l = 0;
+#pragma unroll
+        for (int k = 1; k < kLM; ++k) if (k < L && pix >= tc.woff[k]) l = k;
+        const int r = pix - tc.woff[l], ww = tc.ww[l];
+        const int dy = (int)udiv(r, ww, tc.m_ww[l]), dx = r - dy * ww;
+        const int b3 = boff[l] + dy * (ww + 1) + dx;
+        work = cnt[b3] + cnt[b3 + 1] + cnt[b3 + ww + 1] + cnt[b3 + ww + 2];
+      }
+      const bool nar = work > 0 && work <= kHeavy, wid = work > kHeavy;
+      const unsigned long long bn = __ballot(nar), bw = __ballot(wid);
+      int basen = 0, basew = 0;
+      if (lane == 0) {
+        if (bn) basen = atomicAdd(&n_narrow, __popcll(bn));
+        if (bw) basew = atomicAdd(&n_wide, __popcll(bw));
+      }
+      basen = __builtin_amdgcn_readfirstlane(basen);
+      basew = __builtin_amdgcn_readfirstlane(basew);
+      const unsigned long long below = (1ull << lane) - 1ull;
+      if (nar) task_n[basen + __popcll(bn & below)] = (unsigned short)pix;
+      if (wid) task_w[basew + __popcll(bw & below)] = (unsigned short)pix;
+    }
+  }
+  lds_barrier();
+  S3(3);
+  // (3) the items into their lists
+  {
+    int st[kLM];
+#pragma unroll
+    for (int l = 0; l < kLM; ++l) st[l] = start[max(bin[l], 0)];
+#pragma unroll
+    for (int l = 0; l < kLM; ++l)
+      if (bin[l] >= 0) {
+        SItem it;
+        it.lx = slx[l]; it.ly = sly[l]; it.a = sa[l]; it.q = qloc * D;
+        items[st[l] + slot[l]] = it;
+      }
+  }
+  lds_barrier();
+  S3(4);
+  // (4) sums.  Corner k of a sample is pixel (y0 + (k >> 1), x0 + (k & 1)): pixel (dy, dx) of the window takes corner 3 from bin
+  // (dy, dx), corner 2 from (dy, dx + 1), corner 1 from (dy + 1, dx), corner 0 from (dy + 1, dx + 1) of the bin grid.
+#if defined(EXP_COL3_CUT) && EXP_COL3_CUT == 2
+  if (items[tid].q == 12345678) gvb[0] = 1.f;
+  return;
+#endif
+#if defined(EXP_COL3_CUT) && EXP_COL3_CUT == 3
+  const int nw = 0, nn = n_narrow;
+#elif defined(EXP_COL3_CUT) && EXP_COL3_CUT == 4
+  const int nw = n_wide, nn = 0;
+#else
+  const int nw = n_wide, nn = n_narrow;
+#endif
+  const int grp8 = lane >> 3;
+  const float* gsj = gs + 4 * j;
+  for (int t = wave; t < nw; t += NW) {         // heavy pixels: one wave each, its 8 lane groups stride over the lists
+    const int pix = task_w[t];
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < kLM; ++k) if (k < L && pix >= tc.woff[k]) l = k;
+    const int r = pix - tc.woff[l], ww = tc.ww[l];
+    const int dy = (int)udiv(r, ww, tc.m_ww[l]), dx = r - dy * ww;
+    const int b3 = boff[l] + dy * (ww + 1) + dx;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+      const int bk = b3 + ((k & 2) ? 0 : ww + 1) + ((k & 1) ? 0 : 1);
+      const SItem* lst = items + start[bk];
+      const int n = cnt[bk];
+      const float sy = (k & 2) ? 1.f : -1.f, oy = (k & 2) ? 0.f : 1.f, sx = (k & 1) ? 1.f : -1.f, ox = (k & 1) ? 0.f : 1.f;   // corner weight = (oy + sy ly)(ox + sx lx) a
+      for (int i = grp8; i < n; i += 16) {
+        const bool two = i + 8 < n;
+        const SItem i0 = lst[i], i1 = lst[two ? i + 8 : i];
+        const float4 g0 = ld4(gsj + i0.q), g1 = ld4(gsj + i1.q);
+        const float w0 = (oy + sy * i0.ly) * (ox + sx * i0.lx) * i0.a;
+        const float w1 = two ? (oy + sy * i1.ly) * (ox + sx * i1.lx) * i1.a : 0.f;
+        acc.x += w0 * g0.x + w1 * g1.x; acc.y += w0 * g0.y + w1 * g1.y; acc.z += w0 * g0.z + w1 * g1.z; acc.w += w0 * g0.w + w1 * g1.w;
+      }
+    }
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {          // every lane group ends with the pixel's total
+      acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
+      acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+    }
+    if (lane < D) {                             // lane i: channel i = component i / 8 of lane group i / 8 (whose j is i % 8)
+      const int gpix = tc.S0[l] + (tc.wy0[l] + dy) * tc.W[l] + tc.wx0[l] + dx;
+      const float v = grp8 == 0 ? acc.x : grp8 == 1 ? acc.y : grp8 == 2 ? acc.z : acc.w;
+      atomicAdd(gvb + (long long)gpix * MD + lane, v);
+    }
+  }
+  S3(5);
+  const int odd = (tid / G) & 1;
+  for (int kk = (tid / (2 * G)) * 2 + odd; kk - odd < nn; kk += GROUPS) {       // light pixels: one lane group each; pairs flush full 64-B lines
+    const bool valid = kk < nn;
+    const int pix = valid ? task_n[kk] : 0;
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < kLM; ++k) if (k < L && pix >= tc.woff[k]) l = k;
+    const int r = pix - tc.woff[l], ww = tc.ww[l];
+    const int dy = (int)udiv(r, ww, tc.m_ww[l]), dx = r - dy * ww;
+    const int b3 = boff[l] + dy * (ww + 1) + dx;
+    const int gpix = valid ? tc.S0[l] + (tc.wy0[l] + dy) * tc.W[l] + tc.wx0[l] + dx : -1;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+      const int bk = b3 + ((k & 2) ? 0 : ww + 1) + ((k & 1) ? 0 : 1);
+      const SItem* lst = items + start[bk];
+      const int n = valid ? cnt[bk] : 0;
+      const float sy = (k & 2) ? 1.f : -1.f, oy = (k & 2) ? 0.f : 1.f, sx = (k & 1) ? 1.f : -1.f, ox = (k & 1) ? 0.f : 1.f;
+      for (int i = 0; i < n; i += 2) {
+        const bool two = i + 1 < n;
+        const SItem i0 = lst[i], i1 = lst[two ? i + 1 : i];
+        const float4 g0 = ld4(gsj + i0.q), g1 = ld4(gsj + i1.q);
+        const float w0 = (oy + sy * i0.ly) * (ox + sx * i0.lx) * i0.a;
+        const float w1 = two ? (oy + sy * i1.ly) * (ox + sx * i1.lx) * i1.a : 0.f;
+        acc.x += w0 * g0.x + w1 * g1.x; acc.y += w0 * g0.y + w1 * g1.y; acc.z += w0 * g0.z + w1 * g1.z; acc.w += w0 * g0.w + w1 * g1.w;
+      }
+    }
+#ifndef EXP_NO_FLUSH
+    {
+      const float send1 = odd ? acc.x : acc.y, send2 = odd ? acc.z : acc.w;
+      const float got1 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send1), 0x128, 0xF, 0xF, true));   // row_ror:8 = lane ^ 8
+      const float got2 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send2), 0x128, 0xF, 0xF, true));
+      const int opx = __builtin_amdgcn_mov_dpp(gpix, 0x128, 0xF, 0xF, true);
+      const int pixA = odd ? opx : gpix, pixB = odd ? gpix : opx;
+      const int jj = j + (odd ? G : 0);
+      if (pixA >= 0) {
+        float* g = gvb + (long long)pixA * MD + jj;
+        atomicAdd(g, odd ? got1 : acc.x);
+        atomicAdd(g + 2 * G, odd ? got2 : acc.z);
+      }
+      if (pixB >= 0) {
+        float* g = gvb + (long long)pixB * MD + jj;
+        atomicAdd(g, odd ? acc.y : got1);
+        atomicAdd(g + 2 * G, odd ? acc.w : got2);
+      }
+    }
+#else
+    if (valid && acc.x + acc.y + acc.z + acc.w == 1.2345f) gvb[gpix] = acc.x;     // timing-only build
+#endif
+  }
+  S3(6);
+  S3_FLUSH;
+}
+
+// ----------------------------------------------------------------------------------------------------------------------
+// Backward-scatter, one pass, PATCH-owned sums (round 4, second step).  Phase cuts of the kernel above (tools/r4_exp5.sh, N = 10, ring
+// offsets): loads + binning 73 us, light-pixel sums 81 us, heavy-pixel sums 63 us of 204 -- (i) the loads were 4- and 8-byte
+// pieces (a thread = one point of every level: 16 wave-level loads of 16 partial lines each) and (ii) the sums are bound by LDS
+// BANDWIDTH: every corner contribution re-reads its query's 128-byte grad_out row, 26 M rows = 3.3 GB = 42 us at 128 B/clk/CU before
+// any inefficiency.  Here
+//   * a thread owns the four POINTS of one (query, level): two 16-byte loads of locations, one of weights; rows come in as 16-byte
+//     pieces and are transposed to the flush layout on their way into LDS;
+//   * the sums are owned by 2 x 2-pixel PATCHES: a lane group keeps the patch's 4 pixels in registers (16 floats per lane), walks
+//     the 3 x 3 bins whose samples can touch the patch and reads each sample's row ONCE for all its corners inside the patch
+//     (2.25 row reads per sample instead of 4), four items in flight; the bin position relative to the patch is a template
+//     parameter, so which accumulators a sample feeds is known at compile time (no predicated FMAs).  (2 x 4 patches = 1.9 reads
+//     per sample were built first: 32 accumulators left no registers for a second item in flight at 6 waves per SIMD.)
+//   * heavy patches (coarse levels) are a wave's task: its 8 lane groups stride over the lists, then a 12-exchange reduce-scatter
+//     leaves pixel g / 2 of the patch with lane groups g, g ^ 1, and the even ones flush.
+struct __attribute__((aligned(16))) PItem {
+  float wy0, wy1;   // (1 - ly) * a, ly * a
+  float lx;
+  int q;            // float offset of the query's staged grad_out row
+};
+
+#ifndef EXP_HEAVYP
+#define EXP_HEAVYP 64
+#endif
+constexpr int kHeavyP = EXP_HEAVYP;        // sample reads from which a patch becomes a whole wave's task
+constexpr int kPatchMax = 512;
+
+// One bin of a patch.  The bin's position (BY, BX) relative to the patch is static, so which accumulators a sample feeds is known at
+// compile time.  Four items in flight per trip.  (Also built and measured, tools/r4_exp9.sh: the three bins of a bin row as ONE contiguous
+// run of items -- they are consecutive in the scan order -- with the bin column carried in the item: 7 instead of 27 dependent LDS round
+// trips per patch, but four selects per item for the column weights: 192 against 177 us.  The sums are bound by instruction issue at
+// low lane efficiency -- lane groups of a wave walk lists of different lengths -- not by LDS latency or bandwidth.)
+template <int BY, int BX, int step>
+__device__ __forceinline__ void patch_bin_sum(const PItem* __restrict__ lst, int n, int first, const float* __restrict__ gsj,
+                                              float4 (&acc)[4]) {
+  for (int i = first; i < n; i += 4 * step) {
+    PItem it[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) it[u] = lst[min(i + u * step, n - 1)];
+    float4 g[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) g[u] = ld4(gsj + it[u].q);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool on = i + u * step < n;
+      const float wy[2] = {on ? it[u].wy0 : 0.f, on ? it[u].wy1 : 0.f};
+      const float wx[2] = {1.f - it[u].lx, it[u].lx};
+#pragma unroll
+      for (int cy = 0; cy < 2; ++cy) {
+        const int py = BY - 1 + cy;
+        if (py < 0 || py > 1) continue;
+#pragma unroll
+        for (int cx = 0; cx < 2; ++cx) {
+          const int px = BX - 1 + cx;
+          if (px < 0 || px > 1) continue;
+          const float w = wy[cy] * wx[cx];
+          float4& a = acc[py * 2 + px];
+          a.x += w * g[u].x; a.y += w * g[u].y; a.z += w * g[u].z; a.w += w * g[u].w;
+        }
+      }
+    }
+  }
+}
+
+// two neighbouring lane groups (16 lanes) flush their pixels together: every atomic request carries a full 64-byte line of ONE pixel
+__device__ __forceinline__ void pair_flush(const float4& acc, int gpix, int odd, int j, float* __restrict__ gvb, int MD) {
+#ifdef EXP_NO_FLUSH
+  if (gpix >= 0 && acc.x + acc.y + acc.z + acc.w == 1.2345f) gvb[gpix] = acc.x;     // timing-only build: keeps the sums alive, never stores
+  return;
+#endif
+  const float send1 = odd ? acc.x : acc.y, send2 = odd ? acc.z : acc.w;
+  const float got1 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send1), 0x128, 0xF, 0xF, true));   // row_ror:8 = lane ^ 8
+  const float got2 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send2), 0x128, 0xF, 0xF, true));
+  const int opx = __builtin_amdgcn_mov_dpp(gpix, 0x128, 0xF, 0xF, true);
+  const int pixA = odd ? opx : gpix, pixB = odd ? gpix : opx;
+  const int jj = j + (odd ? 8 : 0);
+  if (pixA >= 0) {
+    float* g = gvb + (long long)pixA * MD + jj;
+    atomicAdd(g, odd ? got1 : acc.x);
+    atomicAdd(g + 16, odd ? got2 : acc.z);
+  }
+  if (pixB >= 0) {
+    float* g = gvb + (long long)pixB * MD + jj;
+    atomicAdd(g, odd ? acc.y : got1);
+    atomicAdd(g + 16, odd ? acc.w : got2);
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT, 6) void k_scatter_col4(const float* __restrict__ loc, const float* __restrict__ attn,
+                                                         const float* __restrict__ gout, int S, int M, ColGeom geo,
+                                                         float* __restrict__ gvalue) {
+  constexpr int G = 8, D = 32, P = 4, GROUPS = NT / G, NW = NT / 64, BPL = kBins3 / 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* gs = reinterpret_cast<float*>(smem);                                             // [tmax][D], channel j + G*c at 4*j + c
+  PItem* items = reinterpret_cast<PItem*>(smem + (size_t)geo.tmax * D * sizeof(float));    // [L * tmax * P]
+  int* qg = reinterpret_cast<int*>(items + (size_t)geo.L * geo.tmax * P);                  // [tmax]
+  __shared__ int cnt[kBins3], start[kBins3 + 1];
+  __shared__ unsigned short task_n[kPatchMax], task_w[kPatchMax];
+  __shared__ int boff[kLM + 1], poff[kLM + 1], pcw[kLM], n_narrow, n_wide;
+  __shared__ unsigned m_pcw[kLM];
+  __shared__ TileCtx tc;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bid = blockIdx.x;
+  const int bt = (int)udiv(bid, M, geo.m_M);
+  const int m = bid - bt * M;
+  const int b = (int)udiv(bt, geo.ntiles, geo.m_ntiles), tile = bt - b * geo.ntiles;
+  for (int i = tid; i < kBins3; i += NT) cnt[i] = 0;
+  if (tid == 0) { n_narrow = 0; n_wide = 0; }
+  tile_setup(geo, tile, tc, tid);
+  const int L = geo.L, NS = L * P, MD = M * D;
+  const int T = tc.qbase[L], TL = T * L;
+  if (tid <= L) {
+    int o = 0, po = 0;
+    for (int k = 0; k < tid; ++k) {
+      o += (tc.wh[k] + 1) * (tc.ww[k] + 1);
+      po += ((tc.wh[k] + 1) >> 1) * ((tc.ww[k] + 1) >> 1);
+    }
+    boff[tid] = o;
+    poff[tid] = po;
+    if (tid < L) {
+      pcw[tid] = (tc.ww[tid] + 1) >> 1;
+      m_pcw[tid] = magic_of((unsigned)((tc.ww[tid] + 1) >> 1));
+    }
+  }
+  for (int i = tid; i < T; i += NT) qg[i] = local_to_query(tc, L, i);
+  __syncthreads();
+  const int j = tid % G;
+  // this thread: the four points of (query ql, level lv)
+  const int ts = min(tid, TL - 1);
+  const int ql = L == 4 ? ts >> 2 : L == 2 ? ts >> 1 : L == 3 ? ts / 3 : ts;
+  const int lv = ts - ql * L;
+  float4 la, lb, wa;
+  {
+    const long long wi = (((long long)b * S + qg[ql]) * M + m) * NS + lv * P;
+    la = ld4(loc + wi * 2); lb = ld4(loc + wi * 2 + 4); wa = ld4(attn + wi);
+  }
+  {
+    float4 gq[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int qr = min(tid / G + u * GROUPS, T - 1);
+      gq[u] = ld4(gout + (((long long)b * S + qg[qr]) * M + m) * D + 4 * j);           // channels 4j .. 4j+3
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int qr = tid / G + u * GROUPS;
+      if (qr < T) {                 // channel c sits at 4 * (c % 8) + c / 8: position 16 * (j & 1) + 4 * i + (j >> 1) for c = 4j + i
+        float* d = gs + qr * D + 16 * (j & 1) + (j >> 1);
+        d[0] = gq[u].x; d[4] = gq[u].y; d[8] = gq[u].z; d[12] = gq[u].w;
+      }
+    }
+  }
+  float* gvb = gvalue + (long long)b * S * MD + m * D;
+  // (1) bin the four samples by their top-left pixel.  bin >= 0: inside the window; bin = -1 - mask: outside (mask = corners inside the map,
+  // 0 = no sample) and `slot` = the corner-0 pixel for the direct path
+  const int lH = tc.H[lv], lW = tc.W[lv];
+  int bin[4], slot[4];
+  float wy0[4], wy1[4], slx[4];
+  {
+    const int wy0_ = tc.wy0[lv], wx0_ = tc.wx0[lv], wh = tc.wh[lv], ww = tc.ww[lv], bo = boff[lv];
+    const float px_[4] = {la.x, la.z, lb.x, lb.z}, py_[4] = {la.y, la.w, lb.y, lb.w}, pa_[4] = {wa.x, wa.y, wa.z, wa.w};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      bin[p] = -1; slot[p] = 0; wy0[p] = 0.f; wy1[p] = 0.f; slx[p] = 0.f;
+      const float h_im = py_[p] * (float)lH - 0.5f, w_im = px_[p] * (float)lW - 0.5f;
+      if (tid < TL && h_im > -1.f && w_im > -1.f && h_im < (float)lH && w_im < (float)lW) {
+        const int y0 = (int)floorf(h_im), x0 = (int)floorf(w_im);
+        const float ly = h_im - (float)y0;
+        slx[p] = w_im - (float)x0;
+        wy0[p] = (1.f - ly) * pa_[p];
+        wy1[p] = ly * pa_[p];
+        const bool in = max(y0, 0) >= wy0_ && min(y0 + 1, lH - 1) < wy0_ + wh && max(x0, 0) >= wx0_ && min(x0 + 1, lW - 1) < wx0_ + ww;
+        if (in) {
+          bin[p] = bo + (y0 - wy0_ + 1) * (ww + 1) + (x0 - wx0_ + 1);
+        } else {
+          const bool y0ok = y0 >= 0, y1ok = y0 + 1 <= lH - 1, x0ok = x0 >= 0, x1ok = x0 + 1 <= lW - 1;
+          bin[p] = -1 - ((y0ok && x0ok ? 1 : 0) | (y0ok && x1ok ? 2 : 0) | (y1ok && x0ok ? 4 : 0) | (y1ok && x1ok ? 8 : 0));
+          slot[p] = y0 * lW + x0;
+        }
+      }
+    }
+  }
+#if defined(EXP_COL4_CUT) && EXP_COL4_CUT == 8
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+    if (bin[p] >= 0) slot[p] = cnt[bin[p]];
+#else
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+    if (bin[p] >= 0) slot[p] = atomicAdd(&cnt[bin[p]], 1);
+#endif
+  __syncthreads();           // gs staged (the direct path below reads it), counts complete
+#if defined(EXP_COL4_CUT) && (EXP_COL4_CUT == 1 || EXP_COL4_CUT == 7 || EXP_COL4_CUT == 8)
+  if (slot[0] + slot[1] + slot[2] + slot[3] + bin[0] + bin[1] + bin[2] + bin[3] == 12345678) gvb[0] = slx[0] + wy0[1] + wy1[2] + gs[tid] + slx[1] + slx[2] + slx[3] + wy0[0] + wy0[2] + wy0[3] + wy1[0] + wy1[1] + wy1[3];
+  return;
+#endif
+#if !(defined(EXP_COL4_CUT) && EXP_COL4_CUT == 9)
+  {
+    // samples outside the window: straight to memory, one sample per wave step, D lanes x 4 B contiguous per corner
+    const int lS0 = tc.S0[lv];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      unsigned long long bal = __ballot(bin[p] < -1);
+      while (bal) {
+        const int src = __ffsll((long long)bal) - 1;
+        bal &= bal - 1;
+        const int om = -1 - __builtin_amdgcn_readlane(bin[p], src), gp = __builtin_amdgcn_readlane(slot[p], src),
+                  qs = __builtin_amdgcn_readlane(ql, src), W = __builtin_amdgcn_readlane(lW, src), s0 = __builtin_amdgcn_readlane(lS0, src);
+        const float lx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(slx[p]), src));
+        const float a0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wy0[p]), src));
+        const float a1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wy1[p]), src));
+        if (lane < D) {
+          const float g = gs[qs * D + 4 * (lane % G) + lane / G];
+          float* gvl = gvb + (long long)s0 * MD + lane;
+          if (om & 1) atomicAdd(gvl + (long long)gp * MD, a0 * (1.f - lx) * g);
+          if (om & 2) atomicAdd(gvl + (long long)(gp + 1) * MD, a0 * lx * g);
+          if (om & 4) atomicAdd(gvl + (long long)(gp + W) * MD, a1 * (1.f - lx) * g);
+          if (om & 8) atomicAdd(gvl + (long long)(gp + W + 1) * MD, a1 * lx * g);
+        }
+      }
+    }
+  }
+#endif
+#if defined(EXP_COL4_CUT) && (EXP_COL4_CUT == 5 || EXP_COL4_CUT == 9)
+  if (slot[0] == 12345678) gvb[0] = slx[0] + wy0[1] + wy1[2] + gs[tid];
+  return;
+#endif
+  // (2) wave 0: list starts of all bins; the other waves: the patch task lists (a patch's work = the counts of its 3 x 3 bins)
+  const int npatch = poff[L];
+  if (wave == 0) {
+    int c[BPL], s = 0;
+#pragma unroll
+    for (int i = 0; i < BPL; ++i) { c[i] = cnt[lane * BPL + i]; s += c[i]; }
+    int inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    int run = inc - s;
+#pragma unroll
+    for (int i = 0; i < BPL; ++i) { start[lane * BPL + i] = run; run += c[i]; }
+    if (lane == 63) start[kBins3] = run;
+  } else {
+    for (int p0 = 0; p0 < npatch; p0 += NT - 64) {
+      const int pt = p0 + tid - 64;
+      int work = 0;
+      if (pt < npatch) {
+        int l = 0;
+#pragma unroll
+        for (int k = 1; k < kLM; ++k) if (k < L && pt >= poff[k]) l = k;
+        const int r = pt - poff[l], ww = tc.ww[l], wh = tc.wh[l];
+        const int pr = (int)udiv(r, pcw[l], m_pcw[l]), pc = r - pr * pcw[l];
+        const int b0 = boff[l] + 2 * pr * (ww + 1) + 2 * pc;
+#pragma unroll
+        for (int by = 0; by < 3; ++by)
+#pragma unroll
+          for (int bx = 0; bx < 3; ++bx)
+            if (2 * pr + by <= wh && 2 * pc + bx <= ww) work += cnt[b0 + by * (ww + 1) + bx];
+      }
+      const bool nar = work > 0 && work <= kHeavyP, wid = work > kHeavyP;
+      const unsigned long long bn = __ballot(nar), bw = __ballot(wid);
+      int basen = 0, basew = 0;
+      if (lane == 0) {
+        if (bn) basen = atomicAdd(&n_narrow, __popcll(bn));
+        if (bw) basew = atomicAdd(&n_wide, __popcll(bw));
+      }
+      basen = __builtin_amdgcn_readfirstlane(basen);
+      basew = __builtin_amdgcn_readfirstlane(basew);
+      const unsigned long long below = (1ull << lane) - 1ull;
+      if (nar) task_n[basen + __popcll(bn & below)] = (unsigned short)pt;
+      if (wid) task_w[basew + __popcll(bw & below)] = (unsigned short)pt;
+    }
+  }
+  lds_barrier();
+#if defined(EXP_COL4_CUT) && EXP_COL4_CUT == 6
+  if (slot[0] + start[tid] + task_n[tid & 255] + task_w[tid & 255] == 12345678) gvb[0] = slx[0] + wy0[1] + wy1[2] + gs[tid];
+  return;
+#endif
+  // (3) the items into their lists
+  {
+    int st[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) st[p] = start[max(bin[p], 0)];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      if (bin[p] >= 0) {
+        PItem it;
+        it.wy0 = wy0[p]; it.wy1 = wy1[p]; it.lx = slx[p]; it.q = ql * D;
+        items[st[p] + slot[p]] = it;
+      }
+  }
+  lds_barrier();
+#if defined(EXP_COL4_CUT) && EXP_COL4_CUT == 2
+  if (items[tid].q == 12345678) gvb[0] = 1.f;
+  return;
+#endif
+  // (4) sums.  Bin (br, bc) of a level's grid holds the samples whose top-left pixel is window pixel (br - 1, bc - 1); patch (pr, pc) owns window
+  // pixels rows 2pr .. 2pr+1, columns 2pc .. 2pc+1 and is touched by bins rows 2pr .. 2pr+2, columns 2pc .. 2pc+2.
+#if defined(EXP_COL4_CUT) && EXP_COL4_CUT == 3
+  const int nw = 0, nn = n_narrow;
+#elif defined(EXP_COL4_CUT) && EXP_COL4_CUT == 4
+  const int nw = n_wide, nn = 0;
+#else
+  const int nw = n_wide, nn = n_narrow;
+#endif
+  const int grp8 = lane >> 3;
+  const int odd = grp8 & 1;
+  const float* gsj = gs + 4 * j;
+#define OCPG_PATCH_BIN(BY, BX)                                                                                     \
+  {                                                                                                                \
+    const bool ok_ = live_ && 2 * pr + BY <= wh && 2 * pc + BX <= ww;                                              \
+    const int bk_ = ok_ ? b0 + BY * (ww + 1) + BX : b0;                                                            \
+    patch_bin_sum<BY, BX, STEP_>(items + start[bk_], ok_ ? cnt[bk_] : 0, first, gsj, acc);                        \
+  }
+#define OCPG_PATCH_ALL                                                                                             \
+  OCPG_PATCH_BIN(0, 0) OCPG_PATCH_BIN(0, 1) OCPG_PATCH_BIN(0, 2) OCPG_PATCH_BIN(1, 0) OCPG_PATCH_BIN(1, 1) OCPG_PATCH_BIN(1, 2)  \
+  OCPG_PATCH_BIN(2, 0) OCPG_PATCH_BIN(2, 1) OCPG_PATCH_BIN(2, 2)
+  for (int t = wave; t < nw; t += NW) {         // heavy patches: one wave each
+    const int pt = task_w[t];
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < kLM; ++k) if (k < L && pt >= poff[k]) l = k;
+    const int r = pt - poff[l], ww = tc.ww[l], wh = tc.wh[l];
+    const int pr = (int)udiv(r, pcw[l], m_pcw[l]), pc = r - pr * pcw[l];
+    const int b0 = boff[l] + 2 * pr * (ww + 1) + 2 * pc;
+    float4 acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int first = grp8;
+    const bool live_ = true;
+#define STEP_ 8
+    OCPG_PATCH_ALL
+#undef STEP_
+    // reduce-scatter over the 8 lane groups: lane groups g, g ^ 1 end with the total of pixel g / 2 of the patch
+    float4 kb[2], kc;
+    {
+      const bool hi = (grp8 & 4) != 0;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float4 keep = hi ? acc[2 + i] : acc[i], send = hi ? acc[i] : acc[2 + i];
+        kb[i] = make_float4(keep.x + __shfl_xor(send.x, 32, 64), keep.y + __shfl_xor(send.y, 32, 64), keep.z + __shfl_xor(send.z, 32, 64),
+                            keep.w + __shfl_xor(send.w, 32, 64));
+      }
+      const bool mid = (grp8 & 2) != 0;
+      const float4 keep = mid ? kb[1] : kb[0], send = mid ? kb[0] : kb[1];
+      kc = make_float4(keep.x + __shfl_xor(send.x, 16, 64), keep.y + __shfl_xor(send.y, 16, 64), keep.z + __shfl_xor(send.z, 16, 64),
+                       keep.w + __shfl_xor(send.w, 16, 64));
+      kc = make_float4(kc.x + __shfl_xor(kc.x, 8, 64), kc.y + __shfl_xor(kc.y, 8, 64), kc.z + __shfl_xor(kc.z, 8, 64), kc.w + __shfl_xor(kc.w, 8, 64));
+    }
+    const int prow = 2 * pr + (grp8 >> 2), pcol = 2 * pc + ((grp8 >> 1) & 1);
+    const bool live = !odd && prow < wh && pcol < ww && (kc.x != 0.f || kc.y != 0.f || kc.z != 0.f || kc.w != 0.f);
+    pair_flush(kc, live ? tc.S0[l] + (tc.wy0[l] + prow) * tc.W[l] + tc.wx0[l] + pcol : -1, odd, j, gvb, MD);
+  }
+  for (int kk = tid / G; kk - odd < nn; kk += GROUPS) {       // light patches: one lane group each (kk - odd: pairs of groups leave the loop together)
+    const bool valid = kk < nn;
+    const int pt = valid ? task_n[kk] : 0;
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < kLM; ++k) if (k < L && pt >= poff[k]) l = k;
+    const int r = pt - poff[l], ww = tc.ww[l], wh = tc.wh[l];
+    const int pr = (int)udiv(r, pcw[l], m_pcw[l]), pc = r - pr * pcw[l];
+    const int b0 = boff[l] + 2 * pr * (ww + 1) + 2 * pc;
+    float4 acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int first = 0;
+    const bool live_ = valid;
+#define STEP_ 1
+    OCPG_PATCH_ALL
+#undef STEP_
+    const int pbase = tc.S0[l] + (tc.wy0[l] + 2 * pr) * tc.W[l] + tc.wx0[l] + 2 * pc, lw = tc.W[l];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool live = valid && 2 * pr + (k >> 1) < wh && 2 * pc + (k & 1) < ww && (acc[k].x != 0.f || acc[k].y != 0.f || acc[k].z != 0.f || acc[k].w != 0.f);
+      pair_flush(acc[k], live ? pbase + (k >> 1) * lw + (k & 1) : -1, odd, j, gvb, MD);
+    }
+  }
+#undef OCPG_PATCH_ALL
+#undef OCPG_PATCH_BIN
+}
+
+inline size_t scatter4_lds(const ColGeom& g) {
+  return (size_t)g.tmax * 32 * sizeof(float) + (size_t)g.L * g.tmax * 4 * sizeof(PItem) + (size_t)g.tmax * sizeof(int);
+}
+
+// the patch kernel: D = 32, P = 4, 768 threads (a thread per (query, level)), bin grids and patches within the static tables
+inline bool scatter4_ok(const ColGeom& g, int D, int P) {
+  if (D != 32 || P != 4 || g.L > kLM || g.tmax * g.L > 768 || g.tmax * 8 > 2 * 768) return false;
+  if (scatter4_lds(g) > 68 * 1024) return false;
+  int bins = 0, patches = 0;
+  for (int l = 0; l < g.L; ++l) {
+    const int rmax = (g.H[l] + g.nty - 1) / g.nty, cmax = (g.W[l] + g.ntx - 1) / g.ntx;
+    const int wh = std::min(g.H[l], std::max(rmax, 1) + g.mlo + g.mhi), ww = std::min(g.W[l], std::max(cmax, 1) + g.mlo + g.mhi);
+    bins += (wh + 1) * (ww + 1);
+    patches += ((wh + 1) / 2) * ((ww + 1) / 2);
+  }
+  return bins <= kBins3 && patches <= kPatchMax;
+}
+
+inline size_t scatter3_lds(const ColGeom& g, int D, int P) {
+  return (size_t)g.tmax * D * sizeof(float) + (size_t)g.L * g.tmax * P * sizeof(SItem) + (size_t)g.tmax * sizeof(int);
+}
+
+// the one-pass kernel: G = 8, 768 threads, every level's bin grid and window pixels within the static tables, LDS for two workgroups per CU
+inline bool scatter3_ok(const ColGeom& g, int D, int P) {
+  if (D != 32 || g.L > kLM || P < 1 || g.tmax * P > 768 || g.tmax * 8 > 2 * 768) return false;
+  if (scatter3_lds(g, D, P) > 68 * 1024) return false;
+  int bins = 0, pix = 0;
+  for (int l = 0; l < g.L; ++l) {
+    const int rmax = (g.H[l] + g.nty - 1) / g.nty, cmax = (g.W[l] + g.ntx - 1) / g.ntx;
+    const int wh = std::min(g.H[l], std::max(rmax, 1) + g.mlo + g.mhi), ww = std::min(g.W[l], std::max(cmax, 1) + g.mlo + g.mhi);
+    bins += (wh + 1) * (ww + 1);
+    pix += wh * ww;
+  }
+  return bins <= kBins3 && pix <= kBins3 && pix <= 0xffff;
+}
+
 inline size_t gather_lds(const ColGeom& g, int D, int P) {
   return (size_t)g.wmax * D * sizeof(float) + (size_t)g.tmax * P * (sizeof(float4) + sizeof(int)) + (size_t)g.tmax * sizeof(int);
 }
@@ -773,7 +1511,7 @@ inline bool scatter2_ok(const ColGeom& g, int D, int P) {
     int px = 0;
     for (int u = l; u < std::min(l + 2, g.L); ++u) {
       const int rmax = (g.H[u] + g.nty - 1) / g.nty, cmax = (g.W[u] + g.ntx - 1) / g.ntx;
-      px += std::min(g.H[u], std::max(rmax, 1) + kMarginLo + kMarginHi) * std::min(g.W[u], std::max(cmax, 1) + kMarginLo + kMarginHi);
+      px += std::min(g.H[u], std::max(rmax, 1) + g.mlo + g.mhi) * std::min(g.W[u], std::max(cmax, 1) + g.mlo + g.mhi);
     }
     if (px > 768) return false;
   }
@@ -799,7 +1537,7 @@ inline int scatter_threads(const ColGeom& g, int D, int P) {
 
 }  // namespace
 
-bool make_col_geom(const int64_t* sh, int L, int S, int M, int P, int tile_h, int tile_w, ColGeom& g) {
+bool make_col_geom(const int64_t* sh, int L, int S, int M, int P, int tile_h, int tile_w, ColGeom& g, int margin_lo, int margin_hi) {
   if (!sh || L < 1 || L > kLM || M < 1 || P < 1) return false;
   long long tot = 0, best = -1;
   int base = 0;
@@ -814,6 +1552,8 @@ bool make_col_geom(const int64_t* sh, int L, int S, int M, int P, int tile_h, in
   }
   if (tot != S) return false;
   g.L = L;
+  g.mlo = margin_lo;
+  g.mhi = margin_hi;
   g.nty = (g.H[base] + tile_h - 1) / tile_h;
   g.ntx = (g.W[base] + tile_w - 1) / tile_w;
   g.ntiles = g.nty * g.ntx;
@@ -828,7 +1568,7 @@ bool make_col_geom(const int64_t* sh, int L, int S, int M, int P, int tile_h, in
   for (int l = 0; l < L; ++l) {
     const int rmax = (g.H[l] + g.nty - 1) / g.nty, cmax = (g.W[l] + g.ntx - 1) / g.ntx;
     g.tmax += rmax * cmax;
-    const int wh = std::min(g.H[l], std::max(rmax, 1) + kMarginLo + kMarginHi), ww = std::min(g.W[l], std::max(cmax, 1) + kMarginLo + kMarginHi);
+    const int wh = std::min(g.H[l], std::max(rmax, 1) + g.mlo + g.mhi), ww = std::min(g.W[l], std::max(cmax, 1) + g.mlo + g.mhi);
     g.wmax = std::max(g.wmax, wh * ww);
     if (l > 0) g.wrest += wh * ww;
   }
@@ -850,8 +1590,23 @@ int fwd_col(const float* value, const float* loc, const float* attn, int N, int 
 int bwd_scatter_col(const float* loc, const float* attn, const float* gout, int N, int S, int M, int D, int P, const ColGeom& g,
                     float* gvalue, hipStream_t st) {
   {
-    static const int lp = [] { const char* e = std::getenv("OCPG_MSDA_COL_LP"); return e ? std::atoi(e) : 2; }();     // A/B: levels per pass
-    if (lp == 2 && scatter2_ok(g, D, P)) {
+    const char* e = std::getenv("OCPG_MSDA_COL_LP");      // A/B (read per call: tests toggle it): 4 = one pass, patch-owned sums (default), 3 = one pass, pixel-owned sums, 2 = level pairs, 1 = one level per pass
+    const int lp = e ? std::atoi(e) : 4;
+    if (lp >= 4 && scatter4_ok(g, D, P)) {
+      const size_t lds4 = scatter4_lds(g);
+      if (lds4 > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter_col4<768>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+      k_scatter_col4<768><<<(unsigned)((long long)N * g.ntiles * M), 768, lds4, st>>>(loc, attn, gout, S, M, g, gvalue);
+      return 1;
+    }
+    if (lp >= 3 && scatter3_ok(g, D, P)) {
+      const size_t lds3 = scatter3_lds(g, D, P);
+      if (lds3 > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter_col3<768>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+      k_scatter_col3<768><<<(unsigned)((long long)N * g.ntiles * M), 768, lds3, st>>>(loc, attn, gout, S, M, P, g, gvalue);
+      return 1;
+    }
+    if (lp >= 2 && scatter2_ok(g, D, P)) {
       const size_t lds2 = scatter2_lds(g, D, P);
       if (lds2 > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter_col2<8, 768>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);

@@ -231,7 +231,7 @@ def test_self_attention_kernels_vs_c_oracle(dev, shapes_l):
     dv, dl, da, dg = (t.to(dev) for t in (value, loc, attn, go))
     ds, dls = shapes.to(dev), ls.to(dev)
     ds._ocpg_host = shapes
-    for env in ({}, {"OCPG_MSDA_TILE": "1"}, {"OCPG_MSDA_FWD": "col"}, {"OCPG_MSDA_COL": "0"}):
+    for env in ({}, {"OCPG_MSDA_COL_LP": "2"}, {"OCPG_MSDA_COL_LP": "1"}, {"OCPG_MSDA_TILE": "1"}, {"OCPG_MSDA_FWD": "col"}, {"OCPG_MSDA_COL": "0"}):
         with _env(**env):
             out = ms_deform_attn_forward(dv, ds, dls, dl, da)
             gv, gl, ga = ms_deform_attn_backward(dv, ds, dls, dl, da, dg)

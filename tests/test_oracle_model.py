@@ -52,3 +52,24 @@ def test_eval_tail(golden):
     for k in ("pred_logits", "pred_boxes", "pred_masks", "reference_points"):
         a = MASK_LOGIT_ATOL if k == "pred_masks" else 2e-5
         assert torch.allclose(out[k], g[f"pad_eval_{k}"], rtol=2e-4, atol=a), k
+
+
+def test_fp64_referee_brackets_the_reference_vectors(golden):
+    """The oracle evaluated in float64 (`ocpg_ref.real`) is the referee of the full-size GPU test.  On the tiny fixture it must agree
+    with the reference's own (fp32) outputs as well as the fp32 oracle does -- same assignment, mask logits within the north-star
+    bound -- and the fp32 oracle's distance from it is the fp32 round-off the GPU test then allows the product."""
+    g = golden("e2e_tiny")
+    meta, cfg, P, x, mask, text, targets = _setup(g, "nopad")
+    d = torch.float64
+    with torch.no_grad():
+        o32, l32, t32 = ocpg_ref.train_step_loss(P, cfg, x, mask, text, targets)
+        with ocpg_ref.real(d):
+            o64, l64, t64 = ocpg_ref.train_step_loss(ocpg_ref.as_real(P, d), cfg, x.double(), mask, ocpg_ref.as_real(text, d),
+                                                     ocpg_ref.as_real(targets, d))
+    assert ocpg_ref.REAL == torch.float32
+    assert o64["pred_masks"].dtype == d and torch.equal(o64["main_idx"], g["nopad_main_idx"].flatten())
+    for k in ("pred_masks", "pred_masks_low"):
+        ref = g[f"nopad_{k}"].double()
+        e_ref, e_32 = (o64[k] - ref).abs().max().item(), (o64[k] - o32[k].double()).abs().max().item()
+        assert e_ref <= MASK_LOGIT_ATOL and e_32 <= MASK_LOGIT_ATOL, (k, e_ref, e_32)
+    assert abs(float(t64) - g["nopad_total"].item()) <= 2e-4 * abs(float(t64))
