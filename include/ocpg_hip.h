@@ -77,6 +77,37 @@ int ocpg_msda_bwd_locattn_f32(const float* value, const int64_t* shapes, const i
                               const float* loc, const float* attn, const float* grad_out,
                               int N, int S, int M, int D, int L, int Lq, int P,
                               float* grad_loc, float* grad_attn, void* stream);
+/* ocpg_msda_bwd_value_f32 with PER-CALL PATH SELECTION (round 4; replaces the same reference kernel, cuh:301-403 via cu:83-152, for
+ * grad_value).  Two kernel families serve the self-attention shape: the query-owned column scatter (fastest while the offsets stay
+ * within ~5 pixels of the query, as at initialisation) and the output-tiled kernels (no halo atomics: ahead once training has spread
+ * the offsets).  sel_state: 8 ints of device memory owned by the CALL SITE (one per MSDeformAttn module), zero-filled once and passed
+ * to every call; the kernels keep in it the share of samples that missed the active path's locality assumption and the path the next
+ * call takes (0 = column, 1 = tiled; slots 6 / 7: far and total samples of the last call, for diagnostics).  Both families are launched
+ * on every call and the inactive one's workgroups return at once, so the choice needs no host round trip and survives HIP-graph replay.
+ * NULL state, a shape one of the families does not serve, or a forced path (OCPG_MSDA_TILE / OCPG_MSDA_COL): as ocpg_msda_bwd_value_f32. */
+/* FUSED FRONT END of the MSDeformAttn module (round 4).  Replaces, for self-attention calls with 2-d reference points, the elementwise
+ * passes of models/ops/modules/ms_deform_attn.py:96-110 around the op: softmax over the L*P attention logits, `reference + offset`, and in
+ * the backward the softmax gradient and the concatenation of the offset / logit gradients.
+ *   qproj [N*Lq, 3*M*L*P]  the merged query projection: columns [0, 2*M*L*P) = sampling offsets (M, L, P, 2) ALREADY divided by (W_l, H_l)
+ *                          (the caller folds that division into the projection's weight rows), columns [2*M*L*P, 3*M*L*P) = logits (M, L*P)
+ *   ref   [N*Lq, L, 2]     reference points (x, y), normalised
+ *   _fwd:       out [N, Lq, M*D] as ocpg_msda_fwd_f32, plus the sampling locations loc_out [N, Lq, M, L, P, 2] and the attention weights
+ *               attn_out [N, Lq, M, L, P] it derived (the module returns them; the backward entry points below read them)
+ *   _bwd_qproj: grad_qproj [N*Lq, 3*M*L*P] (overwritten) = [d offsets | d logits] from value / loc / attn / grad_out -- the gather half of
+ *               the backward (ocpg_msda_bwd_locattn_f32) with the softmax backward in its epilogue; grad_value comes from
+ *               ocpg_msda_bwd_value_f32 / _sel_f32 as before.
+ * D = 32 and L*P = 16 only; -2000 otherwise (nothing launched: keep the unfused path). */
+int ocpg_msda_fused_fwd_f32(const float* value, const int64_t* shapes, const int64_t* level_start,
+                            const float* qproj, const float* ref,
+                            int N, int S, int M, int D, int L, int Lq, int P,
+                            float* out, float* loc_out, float* attn_out, void* stream);
+int ocpg_msda_fused_bwd_qproj_f32(const float* value, const int64_t* shapes, const int64_t* level_start,
+                                  const float* loc, const float* attn, const float* grad_out,
+                                  int N, int S, int M, int D, int L, int Lq, int P,
+                                  float* grad_qproj, void* stream);
+int ocpg_msda_bwd_value_sel_f32(const float* loc, const float* attn, const float* grad_out,
+                                int N, int S, int M, int D, int L, int Lq, int P,
+                                float* grad_value, const int64_t* shapes_host, int* sel_state, void* stream);
 int ocpg_msda_bwd_f64(const double* value, const int64_t* shapes, const int64_t* level_start,
                       const double* loc, const double* attn, const double* grad_out,
                       int N, int S, int M, int D, int L, int Lq, int P,

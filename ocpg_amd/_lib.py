@@ -22,6 +22,9 @@ SIGNATURES = {
     "ocpg_msda_fwd_f64": [_vp, _i64p, _i64p, _vp, _vp] + [_int] * 7 + [_vp, _vp],
     "ocpg_msda_bwd_f32": [_vp, _i64p, _i64p, _vp, _vp, _vp] + [_int] * 7 + [_vp, _vp, _vp, _vp, _vp],
     "ocpg_msda_bwd_value_f32": [_vp, _vp, _vp] + [_int] * 7 + [_vp, _vp, _vp],
+    "ocpg_msda_fused_fwd_f32": [_vp, _i64p, _i64p, _vp, _vp] + [_int] * 7 + [_vp, _vp, _vp, _vp],
+    "ocpg_msda_fused_bwd_qproj_f32": [_vp, _i64p, _i64p, _vp, _vp, _vp] + [_int] * 7 + [_vp, _vp],
+    "ocpg_msda_bwd_value_sel_f32": [_vp, _vp, _vp] + [_int] * 7 + [_vp, _vp, _vp, _vp],
     "ocpg_msda_bwd_locattn_f32": [_vp, _i64p, _i64p, _vp, _vp, _vp] + [_int] * 7 + [_vp, _vp, _vp],
     "ocpg_msda_bwd_f64": [_vp, _i64p, _i64p, _vp, _vp, _vp] + [_int] * 7 + [_vp, _vp, _vp, _vp],
     "ocpg_bn_act_fwd": [_vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _int, ctypes.c_longlong, _int, _int, _vp],

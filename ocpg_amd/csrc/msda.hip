@@ -143,6 +143,84 @@ __global__ __launch_bounds__(256) void msda_fwd_fast(const float* __restrict__ v
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Fused front end (round 4): the module's softmax over the L*P attention logits and `reference point + offset`
+// (models/ops/modules/ms_deform_attn.py:96-110, the 2-d reference branch with the offsets already divided by (W_l, H_l) -- the
+// caller folds that division into the projection's 256 weight rows) happen in the row's sample-setup phase, where the lanes compute
+// per-sample scalars anyway.  Input: the merged query projection qproj [N*Lq, 3*M*NS] = [offsets (M, L, P, 2) | logits (M, L*P)] and
+// ref [N*Lq, L, 2].  The sampling locations and attention weights are still WRITTEN (the backward kernels and the module's return
+// value read them) but no longer produced by two elementwise passes and read back: -2 launches, -78 MB read per encoder layer at N = 10.
+// D = 32 (G = 8), L*P = 16: lane j of a row owns samples j and j + 8.
+__global__ __launch_bounds__(256) void msda_fwd_fused8(const float* __restrict__ value, const int64_t* __restrict__ shapes,
+                                                       const int64_t* __restrict__ level_start, const float* __restrict__ qproj,
+                                                       const float* __restrict__ ref, int S, int M, int L, int Lq, int P, long long rows,
+                                                       float* __restrict__ out, float* __restrict__ loc_out, float* __restrict__ attn_out) {
+  constexpr int G = 8, D = 32, ROWS = 256 / G, NS = 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  SampleRec* recs = reinterpret_cast<SampleRec*>(smem);
+  __shared__ int lvlH[kMaxLevels], lvlW[kMaxLevels], lvlS[kMaxLevels];
+  const int tid = threadIdx.x;
+  if (tid < L) {
+    lvlH[tid] = (int)shapes[2 * tid];
+    lvlW[tid] = (int)shapes[2 * tid + 1];
+    lvlS[tid] = (int)level_start[tid];
+  }
+  __syncthreads();
+  const int MD = M * D;
+  const int r = tid / G, j = tid % G;
+  const long long qrow = (long long)(blockIdx.x / M) * ROWS + r;          // flat (b, q); head = block % M (one head per XCD L2, see msda_fwd_fast)
+  const int m = blockIdx.x % M;
+  const long long row = qrow * M + m;
+  const bool live = qrow * M < rows;
+  if (live) {
+    const int QW = 3 * M * NS;
+    const float* qo = qproj + qrow * QW + m * NS * 2;
+    const float* ql = qproj + qrow * QW + M * NS * 2 + m * NS;
+    const float x0 = ql[j], x1 = ql[j + G];
+    float mx = fmaxf(x0, x1);
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    const float e0 = expf(x0 - mx), e1 = expf(x1 - mx);
+    const float den = group_sum<G>(e0 + e1);
+    const float a[2] = {e0 / den, e1 / den};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int sidx = j + u * G, l = sidx / P;
+      const float2 off = *reinterpret_cast<const float2*>(qo + 2 * sidx);
+      const float2 rf = *reinterpret_cast<const float2*>(ref + (qrow * L + l) * 2);
+      const float lx = rf.x + off.x, ly = rf.y + off.y;
+      *reinterpret_cast<float2*>(loc_out + (row * NS + sidx) * 2) = make_float2(lx, ly);
+      attn_out[row * NS + sidx] = a[u];
+      SampleRec rec;
+      make_sample<float>(lx, ly, a[u], lvlH[l], lvlW[l], lvlS[l], MD, rec);
+      recs[r * NS + sidx] = rec;
+    }
+  }
+  __syncthreads();
+  if (!live) return;
+  const long long b = row / ((long long)Lq * M);
+  const float* vbase = value + b * (long long)S * MD + m * D + 4 * j;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const SampleRec* rr = recs + r * NS;
+  for (int sidx = 0; sidx < NS; ++sidx) {
+    const SampleRec rec = rr[sidx];
+    if (rec.mask == 0) continue;  // uniform across the row's lanes
+    const float hy = 1.f - rec.ly, hx = 1.f - rec.lx;
+    const float* p00 = vbase + rec.off00;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 v1 = (rec.mask & 1) ? ld4(p00) : z;
+    const float4 v2 = (rec.mask & 2) ? ld4(p00 + MD) : z;
+    const float4 v3 = (rec.mask & 4) ? ld4(p00 + rec.rowstride) : z;
+    const float4 v4 = (rec.mask & 8) ? ld4(p00 + rec.rowstride + MD) : z;
+    const float w1 = hy * hx, w2 = hy * rec.lx, w3 = rec.ly * hx, w4 = rec.ly * rec.lx;
+    acc.x += (w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x) * rec.a;
+    acc.y += (w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y) * rec.a;
+    acc.z += (w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z) * rec.a;
+    acc.w += (w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w) * rec.a;
+  }
+  *reinterpret_cast<float4*>(out + row * D + 4 * j) = acc;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Generic forward: one wave per row, lanes stride over channels.  Any D, float or double.
 template <typename T>
 __global__ __launch_bounds__(256) void msda_fwd_generic(const T* __restrict__ value, const int64_t* __restrict__ shapes,
@@ -194,7 +272,10 @@ struct __attribute__((aligned(16))) GatherRec {
   float hy, ly, hx, lx;   // masked by validity
 };
 
-template <int G>
+// FUSED (round 4; G = 8, L*P = 16): the epilogue applies the backward of the module's softmax and writes the gradient of the merged query
+// projection [N*Lq, 3*M*NS] = [d offsets | d logits] (gloc = that matrix, gattn unused) instead of grad_loc / grad_attn -- ATen's
+// softmax backward and the `cat` behind the split of the projection (78 MB copied per encoder layer at N = 10) disappear.
+template <int G, bool FUSED = false>
 __global__ __launch_bounds__(256) void msda_bwd_gather_row(const float* __restrict__ value, const int64_t* __restrict__ shapes,
                                                            const int64_t* __restrict__ level_start, const float* __restrict__ loc,
                                                            const float* __restrict__ attn, const float* __restrict__ gout, int S, int M,
@@ -254,7 +335,8 @@ __global__ __launch_bounds__(256) void msda_bwd_gather_row(const float* __restri
   const float4 go = ld4(gout + row * D + 4 * j);
   const GatherRec* rr = recs + r * NS;
   constexpr int NB = 4;
-  for (int s0 = 0; s0 < NS; s0 += NB) {
+  float fga[4] = {0.f, 0.f, 0.f, 0.f}, fgx[4] = {0.f, 0.f, 0.f, 0.f}, fgy[4] = {0.f, 0.f, 0.f, 0.f};      // FUSED: this lane pair's sample of each batch
+  auto batch = [&](const int s0) {
     float red[NB][3];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -279,7 +361,15 @@ __global__ __launch_bounds__(256) void msda_bwd_gather_row(const float* __restri
       red[i][1] = have ? gx : 0.f;
       red[i][2] = have ? gy : 0.f;
     }
-    if (G == 8 && s0 + NB <= NS) {
+    if (FUSED) {
+      float tot[3];
+      (void)reduce_scatter_g8_p4(red, j, tot);       // the lane pair j >> 1 now holds sample s0 + (j >> 1)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {       // (selects, not an indexed store: the batch loop stays rolled -- fully unrolled it took 256 registers)
+        const bool mine = s0 == NB * k;
+        fga[k] = mine ? tot[0] : fga[k]; fgx[k] = mine ? tot[1] : fgx[k]; fgy[k] = mine ? tot[2] : fgy[k];
+      }
+    } else if (G == 8 && s0 + NB <= NS) {
       float tot[3];
       const int sidx = reduce_scatter_g8_p4(red, j, tot);
       if ((j & 1) == 0) {
@@ -297,6 +387,30 @@ __global__ __launch_bounds__(256) void msda_bwd_gather_row(const float* __restri
           gattn[wi] = ga;
           *reinterpret_cast<float2*>(gloc + wi * 2) = make_float2(gx, gy);
         }
+      }
+    }
+  };
+#pragma unroll 1
+  for (int s0 = 0; s0 < NS; s0 += NB) batch(s0);
+  if (FUSED) {
+    // softmax backward over the row's 16 weights: d logit_s = a_s (ga_s - sum_t a_t ga_t); the even lane of pair p holds samples 4k + p
+    const int p = j >> 1;
+    float av[4], dotp = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      av[k] = attn[row * 16 + 4 * k + p];
+      dotp += (j & 1) ? 0.f : av[k] * fga[k];
+    }
+    const float dot = group_sum<G>(dotp);
+    if ((j & 1) == 0) {
+      const int QW = 3 * M * 16;
+      float* go_ = gloc + qrow * QW + (row - qrow * M) * 32;
+      float* gl_ = gloc + qrow * QW + M * 32 + (row - qrow * M) * 16;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int sidx = 4 * k + p;
+        *reinterpret_cast<float2*>(go_ + 2 * sidx) = make_float2(fgx[k], fgy[k]);
+        gl_[sidx] = av[k] * (fga[k] - dot);
       }
     }
   }
@@ -916,7 +1030,7 @@ inline int launch_bwd_locattn_row(const float* value, const int64_t* shapes, con
 
 extern "C" {
 
-const char* ocpg_hip_version(void) { return "ocpg_hip gfx950 r3"; }
+const char* ocpg_hip_version(void) { return "ocpg_hip gfx950 r4"; }
 
 int ocpg_msda_fwd_f32(const float* value, const int64_t* shapes, const int64_t* level_start, const float* loc, const float* attn,
                       int N, int S, int M, int D, int L, int Lq, int P, float* out, const int64_t* shapes_host, void* stream) {
@@ -1048,6 +1162,73 @@ int ocpg_msda_bwd_value_f32(const float* loc, const float* attn, const float* gr
   if (!grad_out) return -1003;
   if (!grad_value) return -1011;
   if (!launch_bwd_value_col(loc, attn, grad_out, shapes_host, N, S, M, D, L, Lq, P, grad_value, (hipStream_t)stream)) return -2000;
+  return launch_status();
+}
+
+// grad_value with per-call path selection (include/ocpg_hip.h).  Both paths' kernels are launched; the call site's state decides on the
+// device which of them runs (csrc/msda_col.h).  Shapes, or forced paths (OCPG_MSDA_TILE / OCPG_MSDA_COL / OCPG_MSDA_COL_LP), that do not
+// allow the choice take the plain entry point's route and leave the state untouched.
+int ocpg_msda_bwd_value_sel_f32(const float* loc, const float* attn, const float* grad_out, int N, int S, int M, int D, int L, int Lq, int P,
+                                float* grad_value, const int64_t* shapes_host, int* sel_state, void* stream) {
+  if (N < 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq < 0 || P <= 0) return -1006;
+  if ((long long)N * Lq == 0) return 0;
+  if (!loc) return -1001;
+  if (!attn) return -1002;
+  if (!grad_out) return -1003;
+  if (!grad_value) return -1011;
+  hipStream_t st = (hipStream_t)stream;
+  const bool forced = std::getenv("OCPG_MSDA_TILE") != nullptr || !col_enabled();
+  if (sel_state && !forced && shapes_host && Lq == S && D == 32 && (long long)S * M * D < (1LL << 31)) {
+    // thresholds (percent of far samples as the ACTIVE family counts them), measured at config #2, N = 10 (tools/bench_msda_gv.py, GV_SELECT=1):
+    //   offsets                      column: far share, us      tiled: far share, us
+    //   initial ring                      0.0 %   169                0.0 %   279
+    //   ring + N(0, 1.5 px) + 2 % far     3.0 %   241                3.6 %   305
+    //   ring + N(0, 3 px) + 5 % far       9.3 %   432               12.5 %   361
+    static const int to_tile = [] { const char* e = std::getenv("OCPG_MSDA_SEL_TO_TILE"); return e ? std::atoi(e) : 6; }();
+    static const int to_col = [] { const char* e = std::getenv("OCPG_MSDA_SEL_TO_COL"); return e ? std::atoi(e) : 6; }();
+    static const int mlo = [] { const char* e = std::getenv("OCPG_MSDA_MARGIN_LO"); return e ? std::atoi(e) : ocpg_col::kScatterMarginLo; }();
+    ocpg_col::ColGeom cg;
+    if (ocpg_col::make_col_geom(shapes_host, L, S, M, P, 8, 16, cg, mlo, ocpg_col::kMarginHi) && ocpg_col::select_supported(cg, D, P) &&
+        ocpg_tile::tile_supported(shapes_host, N, L, S, M, P, D)) {
+      if (ocpg_col::bwd_scatter_col(loc, attn, grad_out, N, S, M, D, P, cg, grad_value, st, sel_state, to_tile) != 2) return -2001;
+      if (!ocpg_tile::bwd_value_tile(loc, attn, grad_out, shapes_host, N, S, M, D, L, P, grad_value, st, sel_state, to_col)) return -2002;
+      ocpg_col::select_commit(sel_state, st);
+      return launch_status();
+    }
+  }
+  if (!launch_bwd_value_col(loc, attn, grad_out, shapes_host, N, S, M, D, L, Lq, P, grad_value, st)) return -2000;
+  return launch_status();
+}
+
+// ---- fused front end (include/ocpg_hip.h): D = 32, L * P = 16; anything else returns -2000 (the caller keeps the unfused path) ----------
+int ocpg_msda_fused_fwd_f32(const float* value, const int64_t* shapes, const int64_t* level_start, const float* qproj, const float* ref,
+                            int N, int S, int M, int D, int L, int Lq, int P, float* out, float* loc_out, float* attn_out, void* stream) {
+  if (int e = check_common(value, shapes, level_start, qproj, ref, N, S, M, D, L, Lq, P)) return e;
+  const long long rows = (long long)N * Lq * M;
+  if (rows == 0) return 0;
+  if (!out) return -1013;
+  if (!loc_out) return -1014;
+  if (!attn_out) return -1015;
+  if (D != 32 || L * P != 16 || L > kMaxLevels || (long long)S * M * D >= (1LL << 31)) return -2000;
+  const int rpb = 256 / 8;
+  const unsigned grid = (unsigned)((((long long)N * Lq + rpb - 1) / rpb) * M);
+  msda_fwd_fused8<<<grid, 256, rpb * 16 * sizeof(SampleRec), (hipStream_t)stream>>>(value, shapes, level_start, qproj, ref, S, M, L, Lq, P, rows, out,
+                                                                                   loc_out, attn_out);
+  return launch_status();
+}
+
+int ocpg_msda_fused_bwd_qproj_f32(const float* value, const int64_t* shapes, const int64_t* level_start, const float* loc, const float* attn,
+                                  const float* grad_out, int N, int S, int M, int D, int L, int Lq, int P, float* grad_qproj, void* stream) {
+  if (int e = check_common(value, shapes, level_start, loc, attn, N, S, M, D, L, Lq, P)) return e;
+  const long long rows = (long long)N * Lq * M;
+  if (rows == 0) return 0;
+  if (!grad_out) return -1013;
+  if (!grad_qproj) return -1014;
+  if (D != 32 || L * P != 16 || L > kMaxLevels || (long long)S * M * D >= (1LL << 31)) return -2000;
+  const int rpb = 256 / 8;
+  const unsigned ggrid = (unsigned)((((long long)N * Lq + rpb - 1) / rpb) * M);
+  msda_bwd_gather_row<8, true><<<ggrid, 256, rpb * (size_t)16 * sizeof(GatherRec), (hipStream_t)stream>>>(value, shapes, level_start, loc, attn, grad_out, S, M, L,
+                                                                                                      Lq, P, rows, grad_qproj, nullptr);
   return launch_status();
 }
 

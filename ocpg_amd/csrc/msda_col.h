@@ -35,10 +35,46 @@ bool make_col_geom(const int64_t* shapes_host, int L, int S, int M, int P, int t
 
 bool scatter_supported(const ColGeom& g, int D, int P);
 
-// Each returns 1 when it launched, 0 when the shape is not supported (nothing launched).
+// ---- per-call path selection between the column scatter (path 0) and the output-tiled kernels (path 1, msda_tile.h) ---------------
+// State of one CALL SITE (a module's backward): 8 ints in device memory, zero-initialised once by the caller and handed to every call.
+// Every call launches both paths' kernels; the workgroups of the path that is not current leave at once (a few microseconds).  The
+// active path counts the samples that miss its locality assumption and proposes the path of the NEXT call (hysteresis: two thresholds);
+// a one-thread kernel at the end of the launch sequence commits the proposal.  No host round trip: the same launches replay inside a HIP graph.
+enum { kSelFar = 0, kSelTotal = 1, kSelTicketA = 2, kSelCur = 3, kSelNext = 4, kSelTicketB = 5, kSelLastFar = 6, kSelLastTotal = 7 };
+
+// The active path's (sampled) workgroups add (far samples, samples) and draw a ticket; the last of them turns the totals into the path
+// proposed for the NEXT call.  The proposal becomes current in a one-thread kernel launched after every kernel of this call (select_commit):
+// no kernel of a call may see the state change under it.
+__device__ __forceinline__ void sel_publish(int* sel, int ticket_slot, int far, int total, int nblocks, int pct, int path_if_over,
+                                            int path_if_under) {
+  if (far) atomicAdd(sel + kSelFar, far);
+  if (total) atomicAdd(sel + kSelTotal, total);
+  __threadfence();
+  if (atomicAdd(sel + ticket_slot, 1) == nblocks - 1) {
+    __threadfence();
+    const int f = atomicAdd(sel + kSelFar, 0), t = atomicAdd(sel + kSelTotal, 0);
+    if (t > 0) {
+      sel[kSelNext] = (long long)f * 100 > (long long)pct * t ? path_if_over : path_if_under;
+      sel[kSelLastFar] = f;
+      sel[kSelLastTotal] = t;
+    }
+    sel[kSelFar] = 0;
+    sel[kSelTotal] = 0;
+    sel[ticket_slot] = 0;
+    __threadfence();
+  }
+}
+
+// last launch of a call that passed `sel`: current path = proposed path
+void select_commit(int* sel, hipStream_t st);
+
+// true: the one-pass patch kernel (the only column kernel that takes part in the selection) serves this geometry
+bool select_supported(const ColGeom& g, int D, int P);
+
+// Each returns 1 (2: the launched kernel honours `sel`) when it launched, 0 when the shape is not supported (nothing launched).
 int fwd_col(const float* value, const float* loc, const float* attn, int N, int S, int M, int D, int P, const ColGeom& g,
             float* out, hipStream_t st);
 int bwd_scatter_col(const float* loc, const float* attn, const float* gout, int N, int S, int M, int D, int P, const ColGeom& g,
-                    float* gvalue, hipStream_t st);
+                    float* gvalue, hipStream_t st, int* sel = nullptr, int to_tile_pct = 0);
 
 }  // namespace ocpg_col

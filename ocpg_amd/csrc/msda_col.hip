@@ -902,10 +902,6 @@ __global__ __launch_bounds__(NT, 6) void k_scatter_col3(const float* __restrict_
       }
     }
   }
-#if defined(EXP_COL3_CUT) && EXP_COL3_CUT == 1
-  if (slot[0] == 12345678) gvb[0] = slx[0] + sly[1] + sa[2] + gs[tid];
-  return;
-#endif
   // (2) wave 0: list starts of all bins; the other waves: the task lists (a pixel's contributions = the counts of its four bins)
   S3(2);
   const int npix = tc.woff[L];
@@ -969,17 +965,7 @@ __global__ __launch_bounds__(NT, 6) void k_scatter_col3(const float* __restrict_
   S3(4);
   // (4) sums.  Corner k of a sample is pixel (y0 + (k >> 1), x0 + (k & 1)): pixel (dy, dx) of the window takes corner 3 from bin
   // (dy, dx), corner 2 from (dy, dx + 1), corner 1 from (dy + 1, dx), corner 0 from (dy + 1, dx + 1) of the bin grid.
-#if defined(EXP_COL3_CUT) && EXP_COL3_CUT == 2
-  if (items[tid].q == 12345678) gvb[0] = 1.f;
-  return;
-#endif
-#if defined(EXP_COL3_CUT) && EXP_COL3_CUT == 3
-  const int nw = 0, nn = n_narrow;
-#elif defined(EXP_COL3_CUT) && EXP_COL3_CUT == 4
-  const int nw = n_wide, nn = 0;
-#else
   const int nw = n_wide, nn = n_narrow;
-#endif
   const int grp8 = lane >> 3;
   const float* gsj = gs + 4 * j;
   for (int t = wave; t < nw; t += NW) {         // heavy pixels: one wave each, its 8 lane groups stride over the lists
@@ -1163,7 +1149,10 @@ __device__ __forceinline__ void pair_flush(const float4& acc, int gpix, int odd,
 template <int NT>
 __global__ __launch_bounds__(NT, 6) void k_scatter_col4(const float* __restrict__ loc, const float* __restrict__ attn,
                                                          const float* __restrict__ gout, int S, int M, ColGeom geo,
-                                                         float* __restrict__ gvalue) {
+                                                         float* __restrict__ gvalue, int* __restrict__ sel, int to_tile_pct) {
+  // path selection (msda_col.h): this kernel is path 0; when the call site's state says the output-tiled kernels serve this call, every
+  // workgroup leaves at once
+  if (sel != nullptr && sel[kSelCur] != 0) return;
   constexpr int G = 8, D = 32, P = 4, GROUPS = NT / G, NW = NT / 64, BPL = kBins3 / 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* gs = reinterpret_cast<float*>(smem);                                             // [tmax][D], channel j + G*c at 4*j + c
@@ -1171,7 +1160,7 @@ __global__ __launch_bounds__(NT, 6) void k_scatter_col4(const float* __restrict_
   int* qg = reinterpret_cast<int*>(items + (size_t)geo.L * geo.tmax * P);                  // [tmax]
   __shared__ int cnt[kBins3], start[kBins3 + 1];
   __shared__ unsigned short task_n[kPatchMax], task_w[kPatchMax];
-  __shared__ int boff[kLM + 1], poff[kLM + 1], pcw[kLM], n_narrow, n_wide;
+  __shared__ int boff[kLM + 1], poff[kLM + 1], pcw[kLM], n_narrow, n_wide, n_far;
   __shared__ unsigned m_pcw[kLM];
   __shared__ TileCtx tc;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1180,7 +1169,7 @@ __global__ __launch_bounds__(NT, 6) void k_scatter_col4(const float* __restrict_
   const int m = bid - bt * M;
   const int b = (int)udiv(bt, geo.ntiles, geo.m_ntiles), tile = bt - b * geo.ntiles;
   for (int i = tid; i < kBins3; i += NT) cnt[i] = 0;
-  if (tid == 0) { n_narrow = 0; n_wide = 0; }
+  if (tid == 0) { n_narrow = 0; n_wide = 0; n_far = 0; }
   tile_setup(geo, tile, tc, tid);
   const int L = geo.L, NS = L * P, MD = M * D;
   const int T = tc.qbase[L], TL = T * L;
@@ -1255,21 +1244,16 @@ __global__ __launch_bounds__(NT, 6) void k_scatter_col4(const float* __restrict_
       }
     }
   }
-#if defined(EXP_COL4_CUT) && EXP_COL4_CUT == 8
-#pragma unroll
-  for (int p = 0; p < 4; ++p)
-    if (bin[p] >= 0) slot[p] = cnt[bin[p]];
-#else
 #pragma unroll
   for (int p = 0; p < 4; ++p)
     if (bin[p] >= 0) slot[p] = atomicAdd(&cnt[bin[p]], 1);
-#endif
+  if (sel != nullptr) {      // this call's share of samples outside the windows: what the NEXT call at this site is dispatched on
+    int nf = 0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) nf += __popcll(__ballot(bin[p] < -1));
+    if (lane == 0 && nf) atomicAdd(&n_far, nf);
+  }
   __syncthreads();           // gs staged (the direct path below reads it), counts complete
-#if defined(EXP_COL4_CUT) && (EXP_COL4_CUT == 1 || EXP_COL4_CUT == 7 || EXP_COL4_CUT == 8)
-  if (slot[0] + slot[1] + slot[2] + slot[3] + bin[0] + bin[1] + bin[2] + bin[3] == 12345678) gvb[0] = slx[0] + wy0[1] + wy1[2] + gs[tid] + slx[1] + slx[2] + slx[3] + wy0[0] + wy0[2] + wy0[3] + wy1[0] + wy1[1] + wy1[3];
-  return;
-#endif
-#if !(defined(EXP_COL4_CUT) && EXP_COL4_CUT == 9)
   {
     // samples outside the window: straight to memory, one sample per wave step, D lanes x 4 B contiguous per corner
     const int lS0 = tc.S0[lv];
@@ -1295,11 +1279,6 @@ __global__ __launch_bounds__(NT, 6) void k_scatter_col4(const float* __restrict_
       }
     }
   }
-#endif
-#if defined(EXP_COL4_CUT) && (EXP_COL4_CUT == 5 || EXP_COL4_CUT == 9)
-  if (slot[0] == 12345678) gvb[0] = slx[0] + wy0[1] + wy1[2] + gs[tid];
-  return;
-#endif
   // (2) wave 0: list starts of all bins; the other waves: the patch task lists (a patch's work = the counts of its 3 x 3 bins)
   const int npatch = poff[L];
   if (wave == 0) {
@@ -1348,10 +1327,6 @@ __global__ __launch_bounds__(NT, 6) void k_scatter_col4(const float* __restrict_
     }
   }
   lds_barrier();
-#if defined(EXP_COL4_CUT) && EXP_COL4_CUT == 6
-  if (slot[0] + start[tid] + task_n[tid & 255] + task_w[tid & 255] == 12345678) gvb[0] = slx[0] + wy0[1] + wy1[2] + gs[tid];
-  return;
-#endif
   // (3) the items into their lists
   {
     int st[4];
@@ -1366,19 +1341,9 @@ __global__ __launch_bounds__(NT, 6) void k_scatter_col4(const float* __restrict_
       }
   }
   lds_barrier();
-#if defined(EXP_COL4_CUT) && EXP_COL4_CUT == 2
-  if (items[tid].q == 12345678) gvb[0] = 1.f;
-  return;
-#endif
   // (4) sums.  Bin (br, bc) of a level's grid holds the samples whose top-left pixel is window pixel (br - 1, bc - 1); patch (pr, pc) owns window
   // pixels rows 2pr .. 2pr+1, columns 2pc .. 2pc+1 and is touched by bins rows 2pr .. 2pr+2, columns 2pc .. 2pc+2.
-#if defined(EXP_COL4_CUT) && EXP_COL4_CUT == 3
-  const int nw = 0, nn = n_narrow;
-#elif defined(EXP_COL4_CUT) && EXP_COL4_CUT == 4
-  const int nw = n_wide, nn = 0;
-#else
   const int nw = n_wide, nn = n_narrow;
-#endif
   const int grp8 = lane >> 3;
   const int odd = grp8 & 1;
   const float* gsj = gs + 4 * j;
@@ -1453,6 +1418,11 @@ __global__ __launch_bounds__(NT, 6) void k_scatter_col4(const float* __restrict_
   }
 #undef OCPG_PATCH_ALL
 #undef OCPG_PATCH_BIN
+  // the call site's statistics, as the LAST thing this workgroup does (the ticket is a returning global atomic: microseconds -- in front of
+  // a barrier it held up all 12 waves: +50 us per launch measured)
+  // Every 16th workgroup reports (2 400 returning atomics on one word are ~27 us of serialised traffic; 150 are not, and 400 k samples
+  // estimate a share well enough).
+  if (sel != nullptr && tid == 0 && (bid & 15) == 0) sel_publish(sel, kSelTicketA, n_far, TL * 4, ((int)gridDim.x + 15) >> 4, to_tile_pct, 1, 0);
 }
 
 inline size_t scatter4_lds(const ColGeom& g) {
@@ -1587,8 +1557,19 @@ int fwd_col(const float* value, const float* loc, const float* attn, int N, int 
   return 1;
 }
 
+__global__ void k_sel_commit(int* sel) {
+  if (threadIdx.x == 0) sel[kSelCur] = sel[kSelNext];
+}
+
+void select_commit(int* sel, hipStream_t st) { k_sel_commit<<<1, 64, 0, st>>>(sel); }
+
+bool select_supported(const ColGeom& g, int D, int P) {
+  const char* e = std::getenv("OCPG_MSDA_COL_LP");
+  return (!e || std::atoi(e) >= 4) && scatter4_ok(g, D, P);
+}
+
 int bwd_scatter_col(const float* loc, const float* attn, const float* gout, int N, int S, int M, int D, int P, const ColGeom& g,
-                    float* gvalue, hipStream_t st) {
+                    float* gvalue, hipStream_t st, int* sel, int to_tile_pct) {
   {
     const char* e = std::getenv("OCPG_MSDA_COL_LP");      // A/B (read per call: tests toggle it): 4 = one pass, patch-owned sums (default), 3 = one pass, pixel-owned sums, 2 = level pairs, 1 = one level per pass
     const int lp = e ? std::atoi(e) : 4;
@@ -1596,8 +1577,8 @@ int bwd_scatter_col(const float* loc, const float* attn, const float* gout, int 
       const size_t lds4 = scatter4_lds(g);
       if (lds4 > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter_col4<768>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
-      k_scatter_col4<768><<<(unsigned)((long long)N * g.ntiles * M), 768, lds4, st>>>(loc, attn, gout, S, M, g, gvalue);
-      return 1;
+      k_scatter_col4<768><<<(unsigned)((long long)N * g.ntiles * M), 768, lds4, st>>>(loc, attn, gout, S, M, g, gvalue, sel, to_tile_pct);
+      return 2;
     }
     if (lp >= 3 && scatter3_ok(g, D, P)) {
       const size_t lds3 = scatter3_lds(g, D, P);

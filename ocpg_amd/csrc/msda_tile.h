@@ -36,7 +36,12 @@ struct TileTab {
 bool make_tile_tab(const int64_t* shapes_host, int N, int L, int S, int M, int P, int D, TileTab& t);
 
 // grad_value (caller zero-fills it) of the self-attention backward; 1 = launched (two kernels), 0 = shape not served
+// sel: the call site's path-selection state (msda_col.h) or null; with it the kernels run only when the state's current path is 1, and the
+// second kernel proposes the next call's path (the caller launches ocpg_col::select_commit after both families)
 int bwd_value_tile(const float* loc, const float* attn, const float* gout, const int64_t* shapes_host, int N, int S, int M, int D, int L,
-                   int P, float* gvalue, hipStream_t st);
+                   int P, float* gvalue, hipStream_t st, int* sel = nullptr, int to_col_pct = 0);
+
+// true: the shape is served (what bwd_value_tile checks before it launches)
+bool tile_supported(const int64_t* shapes_host, int N, int L, int S, int M, int P, int D);
 
 }  // namespace ocpg_tile

@@ -20,6 +20,7 @@
 // sampling locations.  A round = 256 candidate queries x the 4 points of one level: 4 barriers per round with 16 corner
 // contributions per thread between them (round 2: 5 barriers per level with one sample per thread).
 #include "msda_tile.h"
+#include "msda_col.h"       // path-selection state (SelState slots, sel_publish)
 
 #include <algorithm>
 #include <cstdlib>
@@ -207,7 +208,9 @@ struct TileSh {
 };
 
 __global__ __launch_bounds__(NT, 4) void k_gv_tile(const float* __restrict__ loc, const float* __restrict__ attn,
-                                                const float* __restrict__ gout, int S, int M, TileTab tab, float* __restrict__ gvalue) {
+                                                const float* __restrict__ gout, int S, int M, TileTab tab, float* __restrict__ gvalue,
+                                                const int* __restrict__ sel) {
+  if (sel != nullptr && sel[ocpg_col::kSelCur] != 1) return;      // path selection: the column scatter serves this call
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Item* items = reinterpret_cast<Item*>(smem);
   float* gs = reinterpret_cast<float*>(smem + sizeof(Item) * kItems);
@@ -361,7 +364,12 @@ struct CoarseSh {
 
 template <int NPX>
 __global__ __launch_bounds__(NT, NPX <= 10 ? 3 : 1) void k_gv_coarse(const float* __restrict__ loc, const float* __restrict__ attn,
-                                                  const float* __restrict__ gout, int S, int M, TileTab tab, float* __restrict__ gvalue) {
+                                                  const float* __restrict__ gout, int S, int M, TileTab tab, float* __restrict__ gvalue,
+                                                  int* __restrict__ sel, int to_col_pct) {
+  // path selection: runs only when the call site's state says so; it then also proposes the next call's path (stay while the share of
+  // far samples stays above to_col_pct)
+  if (sel != nullptr && sel[ocpg_col::kSelCur] != 1) return;
+  int far_seen = 0, fine_seen = 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Item* items = reinterpret_cast<Item*>(smem);
   float* gs = reinterpret_cast<float*>(smem + sizeof(Item) * kItems);
@@ -427,6 +435,7 @@ __global__ __launch_bounds__(NT, NPX <= 10 ? 3 : 1) void k_gv_coarse(const float
             const float h_im = pts[l].y[p] * (float)H - 0.5f, w_im = pts[l].x[p] * (float)W - 0.5f;
             const bool ok = active && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
             const int y0 = (int)floorf(h_im), x0 = (int)floorf(w_im);
+            fine_seen += ok ? 1 : 0;
             int ovm = 0;
             if (ok) {
 #pragma unroll
@@ -437,6 +446,7 @@ __global__ __launch_bounds__(NT, NPX <= 10 ? 3 : 1) void k_gv_coarse(const float
                 if (inmap && !near) ovm |= 1 << k;
               }
             }
+            far_seen += ovm != 0 ? 1 : 0;
             unsigned long long bal = __ballot(ovm != 0);
             if (bal) {             // (wave-uniform) rare: one far sample per wave step, lanes 0..31 = its 32 channels
               const float ly = h_im - (float)y0, lx = w_im - (float)x0, hy = 1.f - ly, hx = 1.f - lx, a = pts[l].a[p];
@@ -520,6 +530,15 @@ __global__ __launch_bounds__(NT, NPX <= 10 ? 3 : 1) void k_gv_coarse(const float
         }
       }
     }
+  }
+  if (sel != nullptr && (blockIdx.x & 7) == 0) {       // every 8th workgroup's (far, seen) fine-level samples -> the call site's state; the last of them proposes
+    __shared__ int sel_far, sel_seen;
+    if (tid == 0) { sel_far = 0; sel_seen = 0; }
+    __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) { far_seen += __shfl_xor(far_seen, o, 64); fine_seen += __shfl_xor(fine_seen, o, 64); }
+    if (lane == 0) { atomicAdd(&sel_far, far_seen); atomicAdd(&sel_seen, fine_seen); }
+    __syncthreads();
+    if (tid == 0) ocpg_col::sel_publish(sel, ocpg_col::kSelTicketB, sel_far, sel_seen, ((int)gridDim.x + 7) >> 3, to_col_pct, 1, 0);
   }
   STAMP(15);
   STAMP_FLUSH(8);
@@ -626,8 +645,13 @@ bool make_tile_tab(const int64_t* sh, int N, int L, int S, int M, int P, int Dm,
   return true;
 }
 
+bool tile_supported(const int64_t* shapes_host, int N, int L, int S, int M, int P, int Dm) {
+  TileTab tab;
+  return make_tile_tab(shapes_host, N, L, S, M, P, Dm, tab);
+}
+
 int bwd_value_tile(const float* loc, const float* attn, const float* gout, const int64_t* shapes_host, int N, int S, int M, int Dm, int L,
-                   int P, float* gvalue, hipStream_t st) {
+                   int P, float* gvalue, hipStream_t st, int* sel, int to_col_pct) {
   static_assert(sizeof(TileTab) <= 3600, "TileTab travels as a kernel argument (4 KB limit with the other arguments)");
   TileTab tab;
   if (!make_tile_tab(shapes_host, N, L, S, M, P, Dm, tab)) return 0;
@@ -635,16 +659,16 @@ int bwd_value_tile(const float* loc, const float* attn, const float* gout, const
        reinterpret_cast<uintptr_t>(gvalue)) & 15) return 0;
   const size_t ldsA = sizeof(Item) * kItems + sizeof(float) * NB * D + sizeof(TileSh);
   allow_lds(k_gv_tile, ldsA);
-  k_gv_tile<<<(unsigned)((long long)N * tab.ntiles * M), NT, ldsA, st>>>(loc, attn, gout, S, M, tab, gvalue);
+  k_gv_tile<<<(unsigned)((long long)N * tab.ntiles * M), NT, ldsA, st>>>(loc, attn, gout, S, M, tab, gvalue, sel);
   const unsigned gridB = (unsigned)((long long)N * tab.K * M);
   if (tab.nbB <= NGRP * 10) {
     const size_t ldsB = sizeof(Item) * kItems + sizeof(float) * NB * D + sizeof(CoarseSh<10>);
     allow_lds(k_gv_coarse<10>, ldsB);
-    k_gv_coarse<10><<<gridB, NT, ldsB, st>>>(loc, attn, gout, S, M, tab, gvalue);
+    k_gv_coarse<10><<<gridB, NT, ldsB, st>>>(loc, attn, gout, S, M, tab, gvalue, sel, to_col_pct);
   } else {
     const size_t ldsB = sizeof(Item) * kItems + sizeof(float) * NB * D + sizeof(CoarseSh<20>);
     allow_lds(k_gv_coarse<20>, ldsB);
-    k_gv_coarse<20><<<gridB, NT, ldsB, st>>>(loc, attn, gout, S, M, tab, gvalue);
+    k_gv_coarse<20><<<gridB, NT, ldsB, st>>>(loc, attn, gout, S, M, tab, gvalue, sel, to_col_pct);
   }
   return 1;
 }

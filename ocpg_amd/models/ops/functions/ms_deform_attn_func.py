@@ -94,7 +94,9 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     return out
 
 
-def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, im2col_step=64):
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, im2col_step=64, sel_state=None):
+    """sel_state: the call site's path-selection state (int32[8] on the device, zero-filled once; include/ocpg_hip.h
+    ocpg_msda_bwd_value_sel_f32) or None for the fixed default path."""
     for n, t in (("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
                  ("sampling_loc", sampling_loc), ("attn_weight", attn_weight), ("grad_output", grad_output)):
         require_gpu(n, t)
@@ -108,8 +110,13 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         L_ = lib()
         with torch.cuda.device(value.device):
             with _timed("bwd_enc_value"):
-                rc1 = L_.ocpg_msda_bwd_value_f32(sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(), N, S, M, D, L,
-                                                 Lq, P, grad_value.data_ptr(), ctypes.c_void_p(hs.data_ptr()), stream_ptr())
+                if sel_state is not None:
+                    rc1 = L_.ocpg_msda_bwd_value_sel_f32(sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(), N, S, M, D, L,
+                                                         Lq, P, grad_value.data_ptr(), ctypes.c_void_p(hs.data_ptr()), sel_state.data_ptr(),
+                                                         stream_ptr())
+                else:
+                    rc1 = L_.ocpg_msda_bwd_value_f32(sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(), N, S, M, D, L,
+                                                     Lq, P, grad_value.data_ptr(), ctypes.c_void_p(hs.data_ptr()), stream_ptr())
             if rc1 == 0:
                 with _timed("bwd_enc_locattn"):
                     rc2 = L_.ocpg_msda_bwd_locattn_f32(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
@@ -145,6 +152,7 @@ class MSDeformAttnFunction(Function):
                                         attention_weights, im2col_step)
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights)
         ctx.shapes_host = getattr(value_spatial_shapes, "_ocpg_host", None)
+        ctx.sel_state = getattr(sampling_locations, "_ocpg_sel", None)       # the calling module's path-selection state (or None)
         return output
 
     @staticmethod
@@ -153,5 +161,72 @@ class MSDeformAttnFunction(Function):
         value, shapes, level_start, loc, attn = ctx.saved_tensors
         if ctx.shapes_host is not None:
             shapes._ocpg_host = ctx.shapes_host
-        gv, gl, ga = ms_deform_attn_backward(value, shapes, level_start, loc, attn, grad_output.contiguous(), ctx.im2col_step)
+        gv, gl, ga = ms_deform_attn_backward(value, shapes, level_start, loc, attn, grad_output.contiguous(), ctx.im2col_step, ctx.sel_state)
         return gv, None, None, gl, ga, None
+
+
+class MSDeformAttnFusedFunction(Function):
+    """The module's front end fused into the op (include/ocpg_hip.h: ocpg_msda_fused_fwd_f32 / _bwd_qproj_f32): softmax over the L*P logits
+    and `reference + offset` (ms_deform_attn.py:96-110, 2-d reference branch) inside the forward kernel's sample setup, the softmax backward
+    and the [d offsets | d logits] layout inside the gather kernel's epilogue.  Self-attention calls only (Lq == S), D = 32, L*P = 16,
+    reference points without gradient; `supported()` says whether a call qualifies -- the module keeps the unfused path otherwise.
+
+    apply(value [N,S,M,D], shapes, level_start, qproj [N,Lq,3*M*L*P], ref [N,Lq,L,2], L, P, sel_state) -> (out, loc, attn)"""
+
+    @staticmethod
+    def supported(value, qproj, ref, L, P):
+        return (value.is_cuda and value.dtype == torch.float32 and qproj.dtype == torch.float32 and ref.dtype == torch.float32
+                and value.shape[-1] == 32 and L * P == 16 and ref.shape[-1] == 2 and not ref.requires_grad
+                and value.shape[1] == qproj.shape[1] and qproj.is_contiguous())
+
+    @staticmethod
+    def forward(ctx, value, shapes, level_start, qproj, ref, L, P, sel_state):
+        N, S, M, D = value.shape
+        Lq = qproj.shape[1]
+        value, ref = value.contiguous(), ref.contiguous()
+        out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+        loc = torch.empty((N, Lq, M, L, P, 2), dtype=value.dtype, device=value.device)
+        attn = torch.empty((N, Lq, M, L, P), dtype=value.dtype, device=value.device)
+        with torch.cuda.device(value.device), _timed("fwd_enc"):
+            check(lib().ocpg_msda_fused_fwd_f32(value.data_ptr(), shapes.data_ptr(), level_start.data_ptr(), qproj.data_ptr(), ref.data_ptr(),
+                                                N, S, M, D, L, Lq, P, out.data_ptr(), loc.data_ptr(), attn.data_ptr(), stream_ptr()),
+                  "ocpg_msda_fused_fwd")
+        ctx.save_for_backward(value, shapes, level_start, loc, attn)
+        ctx.shapes_host = getattr(shapes, "_ocpg_host", None)
+        ctx.sel_state = sel_state
+        ctx.qshape = qproj.shape
+        ctx.mark_non_differentiable(loc, attn)
+        return out, loc, attn
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output, _gloc, _gattn):
+        value, shapes, level_start, loc, attn = ctx.saved_tensors
+        N, S, M, D = value.shape
+        _, Lq, _, L, P, _ = loc.shape
+        go = grad_output.contiguous()
+        hs = ctx.shapes_host if ctx.shapes_host is not None else _host_shapes(shapes)
+        grad_value = torch.zeros_like(value)
+        grad_q = torch.empty(ctx.qshape, dtype=value.dtype, device=value.device)
+        L_ = lib()
+        with torch.cuda.device(value.device):
+            with _timed("bwd_enc_value"):
+                args = (loc.data_ptr(), attn.data_ptr(), go.data_ptr(), N, S, M, D, L, Lq, P, grad_value.data_ptr(), ctypes.c_void_p(hs.data_ptr()))
+                if ctx.sel_state is not None:
+                    rc = L_.ocpg_msda_bwd_value_sel_f32(*args, ctx.sel_state.data_ptr(), stream_ptr())
+                else:
+                    rc = L_.ocpg_msda_bwd_value_f32(*args, stream_ptr())
+            if rc == -2000:        # shape not served by the self-attention scatter kernels: the whole backward through the generic entry point
+                grad_value.zero_()
+                gl, ga = torch.empty_like(loc), torch.empty_like(attn)
+                check(L_.ocpg_msda_bwd_f32(value.data_ptr(), shapes.data_ptr(), level_start.data_ptr(), loc.data_ptr(), attn.data_ptr(), go.data_ptr(),
+                                           N, S, M, D, L, Lq, P, grad_value.data_ptr(), gl.data_ptr(), ga.data_ptr(), ctypes.c_void_p(hs.data_ptr()),
+                                           stream_ptr()), "ocpg_msda_bwd")
+                glogit = attn.view(N, Lq, M, L * P) * (ga.view(N, Lq, M, L * P) - (attn * ga).view(N, Lq, M, L * P).sum(-1, keepdim=True))
+                grad_q = torch.cat([gl.reshape(N, Lq, -1), glogit.reshape(N, Lq, -1)], -1)
+                return grad_value, None, None, grad_q, None, None, None, None
+            check(rc, "ocpg_msda_bwd_value")
+            with _timed("bwd_enc_locattn"):
+                check(L_.ocpg_msda_fused_bwd_qproj_f32(value.data_ptr(), shapes.data_ptr(), level_start.data_ptr(), loc.data_ptr(), attn.data_ptr(),
+                                                       go.data_ptr(), N, S, M, D, L, Lq, P, grad_q.data_ptr(), stream_ptr()), "ocpg_msda_fused_bwd_qproj")
+        return grad_value, None, None, grad_q, None, None, None, None

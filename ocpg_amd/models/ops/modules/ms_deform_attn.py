@@ -5,6 +5,7 @@ models/ops/modules/ms_deform_attn.py:31-118 (returns (output, sampling_locations
 Runs in fp32 regardless of autocast, as the reference does (deformable_transformer.py:250,329).
 """
 import math
+import os
 import warnings
 
 import torch
@@ -14,8 +15,11 @@ from torch import nn
 from ...amp_cache import TokenLinear, linear
 from ....util.misc import memo
 from ..functions import MSDeformAttnFunction
+from ..functions.ms_deform_attn_func import MSDeformAttnFusedFunction
 
 
+FUSED_FRONT = os.environ.get("OCPG_MSDA_FUSED_FRONT", "1") != "0"   # A/B switch: softmax + location arithmetic (and their backward) inside the op's kernels
+SELECT_PATH = os.environ.get("OCPG_MSDA_SELECT", "1") != "0"     # A/B switch: per-call choice of the grad_value kernel family (self-attention calls)
 MERGED_QUERY_PROJ = True      # A/B switch: sampling_offsets and attention_weights as ONE GEMM over the query (they share their input)
 
 
@@ -38,6 +42,9 @@ class MSDeformAttn(nn.Module):
         self.attention_weights = TokenLinear(d_model, n_heads * n_levels * n_points)
         self.value_proj = TokenLinear(d_model, d_model)
         self.output_proj = TokenLinear(d_model, d_model)
+        # path-selection state of this module's backward (include/ocpg_hip.h: ocpg_msda_bwd_value_sel_f32): which grad_value kernel family the
+        # next call takes, kept on the device by the kernels themselves.  Not part of the state_dict (checkpoints stay interchangeable).
+        self.register_buffer("_sel_state", torch.zeros(8, dtype=torch.int32), persistent=False)
         self._reset_parameters()
 
     def _reset_parameters(self):
@@ -86,6 +93,11 @@ class MSDeformAttn(nn.Module):
                            .expand(M, L, P, 2).reshape(-1).to(query.device))
                 so_w, so_b = so_w * inv[:, None], so_b * inv
             both = linear(query, torch.cat([so_w, self.attention_weights.weight], 0), torch.cat([so_b, self.attention_weights.bias], 0))
+            if (FUSED_FRONT and folded and Lq == S and MSDeformAttnFusedFunction.supported(value, both, reference_points, L, P)):
+                # lines 96-110 of the reference module inside the kernels: no softmax / add / split-cat passes over the [N, Lq, 384] projection
+                out, loc, weights = MSDeformAttnFusedFunction.apply(value.contiguous(), input_spatial_shapes, input_level_start_index, both,
+                                                                    reference_points, L, P, self._sel_state if SELECT_PATH else None)
+                return self.output_proj(out), loc, weights
             off2, logit2 = torch.split(both, [n_off, M * L * P], dim=-1)      # split: its backward is ONE cat (two slices: 2 x (zeros + copy) + add)
             offsets = off2.view(N, Lq, M, L, P, 2)
             weights = F.softmax(logit2.view(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
@@ -103,6 +115,9 @@ class MSDeformAttn(nn.Module):
             loc = reference_points[:, :, None, :, None, :2] + offsets / P * reference_points[:, :, None, :, None, 2:] * 0.5
         else:
             raise ValueError(f"Last dim of reference_points must be 2 or 4, but get {reference_points.shape[-1]} instead.")
+        loc_c = loc.contiguous()
+        if SELECT_PATH and Lq == S and loc_c.is_cuda:
+            loc_c._ocpg_sel = self._sel_state
         out = MSDeformAttnFunction.apply(value.contiguous(), input_spatial_shapes, input_level_start_index,
-                                         loc.contiguous(), weights.contiguous(), self.im2col_step)
+                                         loc_c, weights.contiguous(), self.im2col_step)
         return self.output_proj(out), loc, weights

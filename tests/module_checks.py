@@ -53,7 +53,9 @@ def check_fusion(g, dev, rtol=1e-4, atol=1e-5):
         close(gr, g["gp_" + k], rtol * 10, atol * 50, "fusion gp_" + k)
 
 
-def check_msda_module(g, dev, rtol=1e-4, atol=1e-5):
+def check_msda_module(g, dev, rtol=1e-4, atol=1e-5, host_shapes=False):
+    """host_shapes: the level shapes also travel as a host copy on the tensor (what the product's own transformer does): the self-attention
+    case (r2: Lq == S) then takes the fused front end + the self-attention backward kernels instead of the generic entry points."""
     from ocpg_amd.models.ops.modules import MSDeformAttn
     m = g.meta
     d, L, M, P, N, Lq = m["d"], m["L"], m["M"], m["P"], m["N"], m["Lq"]
@@ -65,6 +67,8 @@ def check_msda_module(g, dev, rtol=1e-4, atol=1e-5):
     pad = g["pad"].to(dev)
     src = synth.rand("mm_src", (N, S, d)).to(dev).requires_grad_(True)
     shapes_d, lsi_d = shapes.to(dev), lsi.to(dev)
+    if host_shapes:
+        shapes_d._ocpg_host = shapes
     for tag, refdim, q_len in (("r2", 2, S), ("r4", 4, Lq)):
         query = synth.rand("mm_q" + tag, (N, q_len, d)).to(dev).requires_grad_(True)
         ref = synth.rand("mm_ref" + tag, (N, q_len, L, refdim), uniform=True)

@@ -56,13 +56,25 @@ def test_msda_module_head_dim_32(golden, dev, strict_hip):
     assert any(k.startswith("ocpg_msda_bwd") for k in strict_hip), strict_hip
 
 
+def test_msda_module_fused_front_end_vs_reference_vectors(golden, dev, strict_hip):
+    """The same reference vectors (ms_deform_attn.py:80-118 run by the reference at 2 heads x 32) through the round-4 FUSED front end: with the
+    host copy of the level shapes attached (as the product's transformer does) the self-attention case computes softmax + `reference +
+    offset` inside ocpg_msda_fused_fwd_f32, the softmax backward + the [d offsets | d logits] layout inside ocpg_msda_fused_bwd_qproj_f32, and
+    grad_value through the path-selecting entry point; output, sampling locations, attention weights and every gradient must match."""
+    mc.check_msda_module(golden("msda_module_d32"), dev, rtol=2e-4, atol=2e-5, host_shapes=True)
+    for sym in ("ocpg_msda_fused_fwd_f32", "ocpg_msda_fused_bwd_qproj_f32", "ocpg_msda_bwd_value_sel_f32"):
+        assert strict_hip.get(sym, 0) >= 1, (sym, strict_hip)
+
+
 def test_transformer_head_dim_32(golden, dev, strict_hip):
     """deformable_transformer.py:134-217 (2 enc + 2 dec layers) at 2 heads x 32: MSDeformAttn <8> kernels, the decoder's
     self-attention through attn_smallk, residual / LayerNorm / FFN glue through csrc/fused_ln.hip."""
     mc.check_transformer(golden("transformer_d32"), dev, rtol=5e-4, atol=5e-5)
     for sym in ("ocpg_msda_fwd_f32", "ocpg_attn_smallk_fwd", "ocpg_attn_smallk_bwd", "ocpg_dropout_add_ln_fwd", "ocpg_bias_relu_dropout_fwd"):
         assert strict_hip.get(sym, 0) >= 1, (sym, strict_hip)
-    assert strict_hip.get("ocpg_msda_bwd_value_f32", 0) >= 1 and strict_hip.get("ocpg_msda_bwd_locattn_f32", 0) >= 1, strict_hip
+    # the encoder's self-attention: fused front end + path-selecting grad_value (round 4); the decoder's cross-attention: the generic entry points
+    for sym in ("ocpg_msda_fused_fwd_f32", "ocpg_msda_fused_bwd_qproj_f32", "ocpg_msda_bwd_value_sel_f32", "ocpg_msda_bwd_f32"):
+        assert strict_hip.get(sym, 0) >= 1, (sym, strict_hip)
 
 
 @pytest.mark.parametrize("bt,q,c,h,w", [(2, 20, 256, 48, 80), (1, 5, 32, 40, 52), (3, 7, 10, 5, 9)])

@@ -278,3 +278,88 @@ def test_self_attention_without_host_shapes(dev):
     g2 = ms_deform_attn_backward(dv, b_, ls.to(dev), dl, da, dg)
     for x, y in zip(g1, g2):
         assert torch.allclose(x, y, rtol=1e-4, atol=1e-5)
+
+
+def test_grad_value_path_selection_follows_the_offsets(dev):
+    """ocpg_msda_bwd_value_sel_f32 (round 4): the call site's state picks the column scatter or the output-tiled kernels ON THE DEVICE from
+    the previous call's share of far samples.  A site that sees spread-out ("trained-like") offsets moves to the tiled kernels on its
+    second call, moves back once the offsets are local again, and every call -- whichever family ran, including the calls on which the
+    state changes -- returns the same grad_value as the fixed path (both are pinned to the C oracle above)."""
+    from ocpg_amd.models.ops.functions import ms_deform_attn_backward
+    shapes_l = [(48, 80), (24, 40), (12, 20), (6, 10)]
+    near = [t.to(dev) if i != 1 else t for i, t in enumerate(_local_inputs(dev, 2, shapes_l, noise=0.3, outliers=0.0, seed=3))]
+    wide = [t.to(dev) if i != 1 else t for i, t in enumerate(_local_inputs(dev, 2, shapes_l, noise=4.0, outliers=0.08, seed=4))]
+    shapes = near[1]
+    ds, dls = shapes.to(dev), near[2]
+    ds._ocpg_host = shapes
+    state = torch.zeros(8, dtype=torch.int32, device=dev)
+    want = {}
+    for name, (value, _, _, loc, attn, go) in (("near", near), ("wide", wide)):
+        want[name] = ms_deform_attn_backward(value, ds, dls, loc, attn, go)[0]
+    seen = []
+    for name in ("near", "wide", "wide", "wide", "near", "near", "near"):
+        value, _, _, loc, attn, go = near if name == "near" else wide
+        ran = int(state[3])                                  # the path THIS call takes
+        gv = ms_deform_attn_backward(value, ds, dls, loc, attn, go, sel_state=state)[0]
+        st = state.tolist()
+        seen.append((name, ran, st[3], st[6], st[7]))
+        assert (gv - want[name]).abs().max() <= 2e-5 * want[name].abs().max(), seen
+        assert st[0] == 0 and st[1] == 0 and st[2] == 0 and st[5] == 0, st     # counters and tickets are reset by the last workgroups
+        assert st[7] > 0 and 0 <= st[6] <= st[7], st
+    paths = [r for _, r, _, _, _ in seen]
+    # call 1 (near) column, proposes column; call 2 (wide) still column, proposes tiled; calls 3-4 tiled; call 5 (near) still tiled, proposes
+    # column; calls 6-7 column
+    assert paths == [0, 0, 1, 1, 1, 0, 0], seen
+    assert seen[1][3] * 100 > 6 * seen[1][4] and seen[0][3] * 100 < 6 * seen[0][4], seen      # far shares: wide above, near below the 6 % threshold (the column kernel's count)
+
+
+@pytest.mark.parametrize("pad", [False, True])
+def test_fused_front_end_equals_the_unfused_module(dev, pad):
+    """MSDeformAttn at the config-#2 encoder shape (8 heads x 32, 4 levels x 4 points, 2 frames) with trained-looking projections: the fused
+    front end (ocpg_msda_fused_*: softmax, `reference + offset`, softmax backward and gradient layout inside the kernels) against the same
+    module with OCPG_MSDA_FUSED_FRONT off (ATen softmax / add / split-cat around the plain entry points): output, locations, weights and
+    the gradients of query, source and all parameters."""
+    from ocpg_amd.models.ops.modules import MSDeformAttn
+    from ocpg_amd.models.ops.modules import ms_deform_attn as mod_file
+    shapes_l = [(48, 80), (24, 40), (12, 20), (6, 10)]
+    shapes, ls = level_start(shapes_l)
+    S = int(shapes.prod(1).sum())
+    g = torch.Generator().manual_seed(11)
+    m = MSDeformAttn(256, 4, 8, 4)
+    with torch.no_grad():
+        m.sampling_offsets.weight.copy_(torch.randn(m.sampling_offsets.weight.shape, generator=g) * 0.05)
+        m.attention_weights.weight.copy_(torch.randn(m.attention_weights.weight.shape, generator=g) * 0.2)
+        m.attention_weights.bias.copy_(torch.randn(m.attention_weights.bias.shape, generator=g) * 0.5)
+    m.to(dev)
+    N = 2
+    refs = []
+    for (h, w) in shapes_l:
+        ys, xs = torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing="ij")
+        refs.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], -1))
+    ref = torch.cat(refs, 0)[None, :, None, :].expand(N, S, 4, 2).contiguous().to(dev)
+    q0 = torch.randn(N, S, 256, generator=g).to(dev)
+    src0 = torch.randn(N, S, 256, generator=g).to(dev)
+    go = torch.randn(N, S, 256, generator=g).to(dev)
+    mask = None
+    if pad:
+        mask = torch.zeros(N, S, dtype=torch.bool)
+        mask[1, 3000:3600] = True
+        mask = mask.to(dev)
+    ds, dls = shapes.to(dev), ls.to(dev)
+    ds._ocpg_host = shapes
+    res = {}
+    for fused in (True, False):
+        old = mod_file.FUSED_FRONT
+        mod_file.FUSED_FRONT = fused
+        try:
+            q, src = q0.clone().requires_grad_(True), src0.clone().requires_grad_(True)
+            m._sel_state.zero_()
+            out, loc, attn = m(q, ref, src, ds, dls, mask)
+            grads = torch.autograd.grad((out * go).sum(), [q, src] + list(m.parameters()))
+            res[fused] = (out, loc, attn) + tuple(grads)
+        finally:
+            mod_file.FUSED_FRONT = old
+    names = ["out", "loc", "attn", "gq", "gsrc"] + ["g_" + n for n, _ in m.named_parameters()]
+    for nm, a, b in zip(names, res[True], res[False]):
+        tol = 2e-5 * b.abs().max().item() + 1e-7
+        assert (a - b).abs().max().item() <= tol, (nm, (a - b).abs().max().item(), b.abs().max().item())

@@ -78,6 +78,36 @@ for mode, (noise, outl) in (("ring", (0.0, 0.0)), ("ring+n", (1.5, 0.02)), ("tra
         res[tile] = gv
         print(json.dumps({"mode": mode, "path": "tile" if tile == "1" else "column", "n_frames": N, "us": round(us, 1),
                           "algorithmic_bytes": algo, "GBs": round(algo / us / 1e3, 1), "frac_of_8TBs": round(algo / us / 1e3 / 8000, 4)}), flush=True)
+    if os.environ.get("GV_SELECT") == "1":        # the per-call selection (ocpg_msda_bwd_value_sel_f32): steady state of a site that keeps seeing this mode
+        os.environ.pop("OCPG_MSDA_TILE", None)
+        state = torch.zeros(8, dtype=torch.int32, device=dev)
+        if os.environ.get("GV_SELECT_START") == "1":          # calibration: start on the tiled path (with OCPG_MSDA_SEL_TO_COL=-1 it stays there)
+            state[3] = 1
+            state[4] = 1
+        gv = torch.zeros(N, S, M, D, device=dev)
+
+        def call():
+            rc = lib().ocpg_msda_bwd_value_sel_f32(loc.data_ptr(), attn.data_ptr(), go.data_ptr(), N, S, M, D, L, S, P, gv.data_ptr(),
+                                                   ctypes.c_void_p(shapes.data_ptr()), state.data_ptr(), stream_ptr())
+            assert rc == 0, rc
+        for _ in range(3):
+            gv.zero_()
+            call()
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(int(os.environ.get("ITERS", "30")))]
+        for a, b in ev:
+            gv.zero_()
+            a.record()
+            call()
+            b.record()
+        torch.cuda.synchronize()
+        us = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)[len(ev) // 2]
+        st = state.tolist()
+        print(json.dumps({"mode": mode, "path": "selected", "runs": "tiled" if st[3] else "column", "far_share_seen_by_it": round(st[6] / max(st[7], 1), 4),
+                          "us": round(us, 1), "frac_of_8TBs": round(algo / us / 1e3 / 8000, 4)}), flush=True)
+        for ref in res.values():
+            d = (gv - ref).abs().max().item() / ref.abs().max().item()
+            assert d < 3e-5, d
     if len(res) == 2 and os.environ.get("GV_NOCHECK") != "1":
         d = (res["1"] - res["0"]).abs().max().item() / res["0"].abs().max().item()
         print(json.dumps({"mode": mode, "tile_vs_column_max_rel": d}), flush=True)
