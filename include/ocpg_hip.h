@@ -219,6 +219,16 @@ long long ocpg_gemm_plans(void);      /* number of cached plans (diagnostics) */
  * how many of them left the first choice; ocpg_gemm_tune_rejected the number of candidates dropped for a differing result. */
 long long ocpg_gemm_tuned(long long* changed);
 long long ocpg_gemm_tune_rejected(void);
+/* Rank-consistent plan choices for data-parallel training (the role of the reference's main.py:62 DistributedDataParallel ranks running
+ * one cuBLAS build: every rank must run the same GEMM kernels, or the slowest rank's choice sets the step).  The candidate timing above is
+ * a per-process measurement, so under N > 1 ranks ONE rank times (ocpg_gemm_set_tuning(0) on the others before their first GEMM),
+ * exports its choices as [key hash, candidate index] pairs, the caller broadcasts them, and every other rank imports them: they apply to
+ * the plans that already exist and to those built later (the heuristic's ranked candidate list is identical on identical hardware).
+ * set_tuning: 1 / 0 = candidate timing on / off in this process, -1 = OCPG_GEMM_TUNE decides.  export: returns the number of pairs
+ * (buf may be NULL to ask for the count); import: 0 on success. */
+void ocpg_gemm_set_tuning(int on);
+long long ocpg_gemm_export_picks(long long* buf, long long cap_pairs);
+int ocpg_gemm_import_picks(const long long* buf, long long n_pairs);
 /* D[M,N] = act(scale[n] * (A W^T)[m,n] + shift[n] (+ skip[m,n])): the 1x1 conv + FrozenBatchNorm2d affine (+ identity) (+ ReLU) of a
  * Bottleneck (models/backbone.py:46-56 + torchvision's block) inside the GEMM epilogue (per-channel alpha vector, fp32 bias, ReLU,
  * beta = 1 on the skip operand).  A [M,K], W [N,K], skip / D [M,N] dense row-major, dtype 0/1/2; scale, shift fp32 [N].

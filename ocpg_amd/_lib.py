@@ -39,6 +39,9 @@ SIGNATURES = {
     "ocpg_gemm_plans": [],
     "ocpg_gemm_tuned": [_vp],
     "ocpg_gemm_tune_rejected": [],
+    "ocpg_gemm_set_tuning": [_int],
+    "ocpg_gemm_export_picks": [_vp, ctypes.c_longlong],
+    "ocpg_gemm_import_picks": [_vp, ctypes.c_longlong],
     "ocpg_window_means3x3_fwd": [_vp, ctypes.c_longlong, _int, _int, _int, _vp, _vp],
     "ocpg_window_means3x3_bwd": [_vp, ctypes.c_longlong, _int, _int, _vp, _vp],
     "ocpg_mso_conv3x3": [_vp, _int, _int, _vp, _int, _vp, _vp, _int, _vp, _int, _vp, _vp, _int] + [_int] * 6 + [_vp],
@@ -101,7 +104,7 @@ SIGNATURES = {
 
 # ---- optional live kernel timing (bench.py): HIP events on the launch stream around every library call ----------
 _TIMING = {"on": False, "events": []}
-_UNTIMED = ("ocpg_colsum_blocks", "ocpg_mso_wgrad_rows", "ocpg_gemm_plans", "ocpg_gemm_tuned", "ocpg_gemm_tune_rejected", "ocpg_bias_relu_dropout_bwd_slots", "ocpg_dropout_add_ln_bwd_slots", "ocpg_groupnorm_cl_work")
+_UNTIMED = ("ocpg_gemm_set_tuning", "ocpg_gemm_export_picks", "ocpg_gemm_import_picks", "ocpg_colsum_blocks", "ocpg_mso_wgrad_rows", "ocpg_gemm_plans", "ocpg_gemm_tuned", "ocpg_gemm_tune_rejected", "ocpg_bias_relu_dropout_bwd_slots", "ocpg_dropout_add_ln_bwd_slots", "ocpg_groupnorm_cl_work")
 
 
 def enable_kernel_timing(on=True):
@@ -190,6 +193,8 @@ def lib():
         L.ocpg_gemm_plans.restype = ctypes.c_longlong
         L.ocpg_gemm_tuned.restype = ctypes.c_longlong
         L.ocpg_gemm_tune_rejected.restype = ctypes.c_longlong
+        L.ocpg_gemm_export_picks.restype = ctypes.c_longlong
+        L.ocpg_gemm_set_tuning.restype = None
         L.ocpg_bias_relu_dropout_bwd_slots.restype = ctypes.c_longlong
         L.ocpg_dropout_add_ln_bwd_slots.restype = ctypes.c_longlong
         L.ocpg_groupnorm_cl_work.restype = ctypes.c_longlong

@@ -80,6 +80,7 @@ struct State {
   long long tuned_plans = 0, tuned_changed = 0, tuned_rejected = 0;
   std::unordered_map<hipStream_t, void*> workspaces;
   std::unordered_map<Key, Plan, KeyHash> plans;
+  std::unordered_map<uint64_t, int> imported;      // key hash -> candidate index chosen by ANOTHER rank (ocpg_gemm_import_picks)
 };
 State* state() {
   static State table[kMaxDevices];
@@ -118,12 +119,13 @@ bool tuning_fp32() {      // experiment switch (default off): also time fp32 pla
   return on;
 }
 
+int g_tuning_override = -1;       // ocpg_gemm_set_tuning: -1 = the environment decides
 bool tuning() {
   static const bool on = [] {
     const char* e = getenv("OCPG_GEMM_TUNE");
     return !(e && e[0] == '0');
   }();
-  return on;
+  return g_tuning_override < 0 ? on : g_tuning_override != 0;
 }
 
 Plan& plan_for(State& s, const Key& key) {
@@ -134,6 +136,12 @@ Plan& plan_for(State& s, const Key& key) {
       s.plans.clear();
     }
     it = s.plans.emplace(key, build(s, key)).first;
+    auto im = s.imported.find((uint64_t)KeyHash()(key));
+    if (im != s.imported.end()) {       // the tuning rank's choice for this shape (the ranked candidate list is the same on every rank)
+      Plan& p = it->second;
+      if (im->second >= 0 && im->second < p.ncand) { p.algo = p.cand[im->second]; p.workspace = p.cand_ws[im->second]; p.picked = im->second; }
+      p.tuned = true;
+    }
   }
   return it->second;
 }
@@ -468,6 +476,37 @@ extern "C" long long ocpg_gemm_tuned(long long* changed) {      // plans of the 
   std::lock_guard<std::mutex> lock(sp->mu);
   if (changed) *changed = sp->tuned_changed;
   return sp->tuned_plans;
+}
+
+// ---- rank-consistent plan choices (multi-GPU data parallel: one rank times the candidates, every rank runs its winners) ------------------
+extern "C" void ocpg_gemm_set_tuning(int on) { g_tuning_override = on; }      // 1 / 0: candidate timing on / off in this process; -1: OCPG_GEMM_TUNE decides
+
+extern "C" long long ocpg_gemm_export_picks(long long* buf, long long cap_pairs) {      // [key hash, candidate index] of every timed plan; returns the pair count
+  State* sp = state();
+  if (!sp) return -1;
+  std::lock_guard<std::mutex> lock(sp->mu);
+  long long n = 0;
+  for (auto& kv : sp->plans) {
+    if (!kv.second.tuned || kv.second.ncand <= 1) continue;
+    if (buf && n < cap_pairs) { buf[2 * n] = (long long)KeyHash()(kv.first); buf[2 * n + 1] = kv.second.picked; }
+    ++n;
+  }
+  return n;
+}
+
+extern "C" int ocpg_gemm_import_picks(const long long* buf, long long n_pairs) {      // applies to the plans that exist and to those built later
+  State* sp = state();
+  if (!sp || (n_pairs > 0 && !buf)) return -1;
+  std::lock_guard<std::mutex> lock(sp->mu);
+  for (long long i = 0; i < n_pairs; ++i) sp->imported[(uint64_t)buf[2 * i]] = (int)buf[2 * i + 1];
+  for (auto& kv : sp->plans) {
+    auto im = sp->imported.find((uint64_t)KeyHash()(kv.first));
+    if (im == sp->imported.end()) continue;
+    Plan& p = kv.second;
+    if (im->second >= 0 && im->second < p.ncand) { p.algo = p.cand[im->second]; p.workspace = p.cand_ws[im->second]; p.picked = im->second; }
+    p.tuned = true;
+  }
+  return 0;
 }
 
 extern "C" long long ocpg_gemm_plans(void) {      // of the current device

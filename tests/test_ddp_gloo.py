@@ -316,3 +316,99 @@ def test_segmented_graph_step_reduce_path_two_ranks():
         assert p.exitcode == 0
     for rank, err in res:
         assert err <= 1e-6, (rank, err)
+
+
+def _ladder_worker(rank, world, port, q, scenario):
+    _setup_paths()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    import bench
+    resets, built, steps = [], [], []
+
+    class Step:
+        def __init__(self, name, fail_step_on=None):
+            self.name, self.fail_step_on = name, fail_step_on
+
+        def __call__(self):
+            t = torch.ones(1)
+            dist.all_reduce(t)                        # the step's gradient collective: every rank must be inside
+            steps.append(self.name)
+            if self.fail_step_on == rank:
+                return torch.tensor(float("nan"))
+            return torch.tensor(1.0)
+
+    def make(name, fail_build_on=None, fail_step_on=None):
+        def build():
+            built.append(name)
+            if fail_build_on == rank:
+                raise RuntimeError(f"capture of {name} failed on rank {rank}")
+            return Step(name, fail_step_on)
+        return (name, build)
+    rungs = {"second": [make("seg", fail_build_on=1), make("single")],                         # rank 1 cannot capture the first mode
+             "third": [make("seg", fail_build_on=0), make("single", fail_step_on=1)],          # ... and the second turns non-finite on rank 1
+             "first": [make("seg"), make("single")]}[scenario]
+    label, step = bench.choose_step(rungs, world, torch.device("cpu"), lambda: resets.append(1), trial_steps=2, log=lambda m: None)
+    q.put((rank, label, list(built), list(steps), len(resets)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("scenario,want", [("first", "seg"), ("second", "single"), ("third", None)])
+def test_launch_mode_ladder_two_ranks(scenario, want):
+    """bench.choose_step: segmented graphs -> single graph -> eager.  A launch mode counts only if it captured AND survived its trial
+    steps on EVERY rank (MIN all-reduce votes): when rank 1 cannot capture the first mode both ranks land on the second; when that one
+    turns non-finite on one rank both fall through to eager (None) -- no rank is ever left alone in a collective, nothing hangs, and a
+    rank that succeeded alone resets and follows."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ladder_worker, args=(r, 2, port, q, scenario)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, l0, b0, s0, n0), (r1, l1, b1, s1, n1) = res
+    assert l0 == l1 == want, res
+    assert b0 == b1, res                                            # both ranks tried the same rungs in the same order
+    assert s0 == s1, res                                            # ... and ran the same trial steps (no rank stepped alone)
+    if scenario == "first":
+        assert b0 == ["seg"] and n0 == n1 == 0
+    if scenario == "second":
+        assert b0 == ["seg", "single"] and s0 == ["single", "single"] and n0 == n1 == 1
+    if scenario == "third":
+        assert n0 == n1 == 2 and s0 == ["single", "single"]
+
+
+def _picks_worker(rank, world, port, q):
+    _setup_paths()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ocpg_amd.util import gemm_sync
+    mine = torch.tensor([[11 + rank, 3], [-(1 << 62) + 5, 0], [77, 7]], dtype=torch.int64) if rank == 0 else torch.tensor([[99, 9]], dtype=torch.int64)
+    got = []
+    n = gemm_sync.share(torch.device("cpu"), src=0, export=lambda: mine, apply=lambda t: got.append(t.clone()))
+    q.put((rank, n, [t.tolist() for t in got]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_gemm_plan_choices_are_broadcast_from_rank0():
+    """ocpg_amd.util.gemm_sync.share: rank 0's (plan key hash, candidate index) pairs reach every other rank unchanged (64-bit hashes
+    included) and are applied there; rank 0 applies nothing; a rank's own timings never travel."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_picks_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0] == (0, 3, [])
+    assert res[1] == (1, 3, [[[11, 3], [-(1 << 62) + 5, 0], [77, 7]]])

@@ -65,7 +65,7 @@ g = torch.Generator().manual_seed(1)
 attn = torch.softmax(torch.randn(N, S, M, L * P, generator=g), -1).view(N, S, M, L, P).to(dev)
 go = torch.randn(N, S, M * D, generator=g).to(dev)
 MODES = os.environ.get("GV_MODES", "ring,ring+n,trained").split(",")
-PATHS = os.environ.get("GV_PATHS", "1,0").split(",")
+PATHS = [p_ for p_ in os.environ.get("GV_PATHS", "1,0").split(",") if p_]
 for mode, (noise, outl) in (("ring", (0.0, 0.0)), ("ring+n", (1.5, 0.02)), ("trained", (3.0, 0.05))):
     if mode not in MODES:
         continue
