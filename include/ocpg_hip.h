@@ -198,6 +198,23 @@ int ocpg_conv3x3_mfma_fwd_cols(const void* x, const void* w, const float* scale,
                                int Cout, int stride, void* y, void* cols, void* stream);
 int ocpg_conv3x3_mfma_dgrad(const void* dy, const void* wT, int N, int H, int W, int Cin, int Cout, int stride, void* dx,
                             void* stream);
+/* ocpg_conv3x3_mfma_dgrad that ALSO applies the frozen-BN + ReLU backward of the layer in front (round 4; FrozenBatchNorm2d backbone.py:46-56
+ * + ReLU of torchvision's Bottleneck between conv1 and conv2): dx[n,h,w,ci] = conv_transpose(dy)[n,h,w,ci] * scale[ci] where
+ * mask_y[n,h,w,ci] > 0, else 0.  mask_y = that layer's post-ReLU output (the convolution's own input), bf16, laid out like dx; scale fp32
+ * [Cin] or NULL (= 1).  Saves one ocpg_bn_act_bwd pass per bottleneck. */
+int ocpg_conv3x3_mfma_dgrad_masked(const void* dy, const void* wT, const void* mask_y, const float* scale, int N, int H, int W, int Cin,
+                                   int Cout, int stride, void* dx, void* stream);
+
+/* Split-K form of ocpg_conv3x3_mfma_fwd for convolutions with FEW output pixels and a LONG reduction (round 4): the neck's extra level
+ * input_proj[3] = nn.Conv2d(2048, 256, 3, stride=2, padding=1) (models/ocpg.py:119-123; 600 output pixels at config #2, K = 18 432) --
+ * MIOpen's split-K kernel until round 3.  blockIdx.z takes a contiguous range of 64-channel chunks; the tiles leave as fp32 partial
+ * sums part[splits][N*Ho*Wo][Cout] (caller-provided scratch, fully written) and a second kernel adds them and the bias into
+ * y [N,Ho,Wo,Cout] (out_dt 0 fp32 / 1 bf16).  ocpg_conv3x3_mfma_splits: the number of ranges to use for a shape (1 = the plain kernel
+ * fills the chip: call ocpg_conv3x3_mfma_fwd).  cols (may be NULL): the patch matrix, as ocpg_conv3x3_mfma_fwd_cols writes it.  The input
+ * gradient is ocpg_conv3x3_mfma_dgrad (its GEMM has N*H*W rows: no split needed). */
+int ocpg_conv3x3_mfma_splits(int N, int H, int W, int Cin, int Cout, int stride);
+int ocpg_conv3x3_mfma_fwd_splitk(const void* x, const void* w, const float* bias, int N, int H, int W, int Cin, int Cout, int stride,
+                                 int splits, float* part, void* y, int out_dt, void* cols, void* stream);
 
 /* Dense GEMM with a per-shape plan cache over hipBLASLt -- replaces the at::mm / at::addmm / at::bmm calls behind
  * nn.Linear and the 1x1 nn.Conv2d layers on the path (models/deformable_transformer.py:236-257,313-327 FFNs,

@@ -61,10 +61,18 @@ __device__ __forceinline__ bool tap_source(const ConvGeom& g, int y, int x, int 
   }
 }
 
-template <bool DGRAD, int BN>
+// SPLITK (64-column tiles only; round 4): blockIdx.z takes a contiguous range of the 64-channel chunks of K and the tile leaves as fp32
+// partial sums part[z][row][col] (y = that buffer; no affine / ReLU: ocpg_splitk_reduce finishes) -- for convolutions whose GEMM has few
+// rows and a long K: the neck's stride-2 level (models/ocpg.py:119-123: 600 output pixels x 256 channels, K = 18 432 = 288 steps on 40
+// workgroups without the split).
+template <bool DGRAD, int BN, bool SPLITK = false>
 __global__ __launch_bounds__(NT) void conv3x3_mfma(const __hip_bfloat16* __restrict__ x, const __hip_bfloat16* __restrict__ w,
                                                    const float* __restrict__ scale, const float* __restrict__ bias, int relu, ConvGeom g,
-                                                   __hip_bfloat16* __restrict__ y, __hip_bfloat16* __restrict__ cols) {
+                                                   __hip_bfloat16* __restrict__ y, __hip_bfloat16* __restrict__ cols,
+                                                   const __hip_bfloat16* __restrict__ mask = nullptr) {
+  // mask (round 4; same [row][column] layout as y, or null): an element is kept only where mask > 0 -- the input-gradient launch then ALSO
+  // does the frozen-BN + ReLU backward of the layer in front (gz = gx * scale[c] * [y_prev > 0], csrc/bn_act.hip's job until round 3)
+  static_assert(!SPLITK || BN == 64, "the split-K epilogue is the 64-column one");
   constexpr int B_L = BN / ROWS_PER_PASS, NJ = BN / 64, WN = BN / 2;      // a wave's tile: 32 rows x WN columns = NJ MFMA tiles
   // 64-column tiles: the four waves split the K STEP instead of the tile (wave w takes the 16-wide slice w of every 64-wide step and
   // accumulates the whole 64 x 64 tile = 2 x 2 MFMA tiles): two A and two B fragments feed four MFMAs, where a 32 x 32 wave tile reads
@@ -96,7 +104,10 @@ __global__ __launch_bounds__(NT) void conv3x3_mfma(const __hip_bfloat16* __restr
       px[i] = r - py[i] * g.W;
     }
   }
-  const int C = g.C, ksteps_per_tap = C / BK, ksteps = 9 * ksteps_per_tap;
+  const int C = g.C, ksteps_per_tap = C / BK;
+  const int cps = SPLITK ? ksteps_per_tap / (int)gridDim.z : ksteps_per_tap;      // 64-channel chunks of this workgroup (the host made it divide)
+  const int c_lo = SPLITK ? (int)blockIdx.z * cps : 0, c_hi = c_lo + cps;
+  const int ksteps = 9 * cps;
   const long long wrow_stride = 9LL * C;                   // elements between consecutive GEMM-N rows of the weight operand
   const __hip_bfloat16* wp[B_L];                           // rows past Cout are clamped: their columns are never stored
 #pragma unroll
@@ -108,7 +119,7 @@ __global__ __launch_bounds__(NT) void conv3x3_mfma(const __hip_bfloat16* __restr
   // s_waitcnt and serialises the batch.
   struct Regs { uint4 a[A_L], b[B_L]; unsigned z; int coff; };     // z bit i: A row i of this set is zero padding; coff: its column in the patch matrix (-1: past the end)
   Regs S0, S1;
-  int f_tap = 0, f_c = 0;                                  // K position of the NEXT fetch (fetches are issued in K order)
+  int f_tap = 0, f_c = c_lo;                               // K position of the NEXT fetch (fetches are issued in K order)
   // Fetches are UNCONDITIONAL, also past the last K step (clamped to the last tap: valid memory, never parked into a buffer that is
   // read): with `if (s + 3 < ksteps) fetch(...)` the compiler has to assume the path on which the fetch did not happen, on which the
   // register set about to be parked holds the MOST RECENT loads -- it then waits with vmcnt(3..0), i.e. also for the four loads issued
@@ -118,10 +129,10 @@ __global__ __launch_bounds__(NT) void conv3x3_mfma(const __hip_bfloat16* __restr
     // K order: the nine taps of one 64-channel chunk, then the next chunk -- consecutive steps then read the SAME 128-byte lines of
     // neighbouring pixels (a tap shifts the tile by one pixel or one row), which the L1 still holds; tap-major order re-read every
     // line from L2 nine times, and the launch is bound by the CU's L1-miss bandwidth (10 B/cycle with one workgroup per CU, 19 with three)
-    const int tap = f_tap, fc = min(f_c, ksteps_per_tap - 1);
+    const int tap = f_tap, fc = min(f_c, c_hi - 1);
     const int ky = (tap * 11) >> 5, kx = tap - ky * 3;      // tap / 3 for tap < 9
     const int c0 = fc * BK + sseg * 8;
-    R.coff = f_c < ksteps_per_tap ? tap * C + c0 : -1;
+    R.coff = f_c < c_hi ? tap * C + c0 : -1;
     z = 0;
 #pragma unroll
     for (int i = 0; i < A_L; ++i) {
@@ -239,6 +250,16 @@ __global__ __launch_bounds__(NT) void conv3x3_mfma(const __hip_bfloat16* __restr
       const int r = (m & 3) + 4 * ((m & 31) >> 3), h = ((m & 31) >> 2) & 1, t0 = (m >> 5) * 2 + (nq >> 5);
       const float* src = red + (t0 * 16 + r) * 64 + (nq & 31) + 32 * h;
       const int col0 = n0 + nq;
+      if constexpr (SPLITK) {                                                   // fp32 partial sums of this K range, 64 bytes per thread
+        float* dst = reinterpret_cast<float*>(y) + ((long long)blockIdx.z * g.M + row) * g.Cout + col0;
+        if (col0 + 16 <= g.Cout && (g.Cout & 3) == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) reinterpret_cast<float4*>(dst)[q] = make_float4(src[4 * q], src[4 * q + 1], src[4 * q + 2], src[4 * q + 3]);
+        } else {
+          for (int j = 0; j < 16 && col0 + j < g.Cout; ++j) dst[j] = src[j];
+        }
+        return;
+      }
       short o[16];
       float sc[16], bi[16];
       const bool full = col0 + 16 <= g.Cout;
@@ -258,10 +279,24 @@ __global__ __launch_bounds__(NT) void conv3x3_mfma(const __hip_bfloat16* __restr
           bi[j] = bias ? bias[col] : 0.f;
         }
       }
+      bool keep[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) keep[j] = true;
+      if (mask) {
+        const __hip_bfloat16* mk = mask + row * g.Cout + col0;
+        if (full && (g.Cout & 7) == 0) {
+          const bf16x8 lo = *reinterpret_cast<const bf16x8*>(mk), hi = *reinterpret_cast<const bf16x8*>(mk + 8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { keep[j] = lo[j] > 0; keep[8 + j] = hi[j] > 0; }      // bf16 > 0 <=> its bits as a signed short > 0
+        } else {
+          for (int j = 0; j < 16 && col0 + j < g.Cout; ++j) keep[j] = reinterpret_cast<const short*>(mk)[j] > 0;
+        }
+      }
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         float v = src[j] * sc[j] + bi[j];                                     // frozen-BN affine / conv bias in the epilogue
         if (relu) v = fmaxf(v, 0.f);
+        if (!keep[j]) v = 0.f;
         o[j] = (short)__bfloat16_as_ushort(__float2bfloat16(v));
       }
       __hip_bfloat16* dst = y + row * g.Cout + col0;
@@ -288,7 +323,10 @@ __global__ __launch_bounds__(NT) void conv3x3_mfma(const __hip_bfloat16* __restr
       const long long row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       float v = acc[j][r] * sv + bv;
       if (relu) v = fmaxf(v, 0.f);
-      if (row < g.M) y[row * g.Cout + col] = __float2bfloat16(v);
+      if (row < g.M) {
+        if (mask && !(reinterpret_cast<const short*>(mask)[row * g.Cout + col] > 0)) v = 0.f;
+        y[row * g.Cout + col] = __float2bfloat16(v);
+      }
     }
   }
 }
@@ -346,16 +384,24 @@ extern "C" int ocpg_conv3x3_mfma_fwd(const void* x, const void* w, const float* 
   return ocpg_conv3x3_mfma_fwd_cols(x, w, scale, bias, relu, N, H, W, Cin, Cout, stride, y, nullptr, stream);
 }
 
-// dy [N,Ho,Wo,Cout] bf16, wT [Cin,3,3,Cout] bf16 (the weight with its channel axes swapped) -> dx [N,H,W,Cin] bf16 fully written
+// dy [N,Ho,Wo,Cout] bf16, wT [Cin,3,3,Cout] bf16 (the weight with its channel axes swapped) -> dx [N,H,W,Cin] bf16 fully written;
+// _masked: dx = conv_transpose(dy) * scale[ci] where mask_y[n,h,w,ci] > 0, else 0 (scale fp32 [Cin] or NULL = 1; mask_y like dx)
+extern "C" int ocpg_conv3x3_mfma_dgrad_masked(const void* dy, const void* wT, const void* mask_y, const float* scale, int N, int H, int W, int Cin,
+                                              int Cout, int stride, void* dx, void* stream);
 extern "C" int ocpg_conv3x3_mfma_dgrad(const void* dy, const void* wT, int N, int H, int W, int Cin, int Cout, int stride, void* dx,
                                        void* stream) {
+  return ocpg_conv3x3_mfma_dgrad_masked(dy, wT, nullptr, nullptr, N, H, W, Cin, Cout, stride, dx, stream);
+}
+
+extern "C" int ocpg_conv3x3_mfma_dgrad_masked(const void* dy, const void* wT, const void* mask_y, const float* scale, int N, int H, int W, int Cin,
+                                              int Cout, int stride, void* dx, void* stream) {
   if (N < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return -1006;
   if ((stride != 1 && stride != 2) || Cout % BK != 0) return -2000;
   if (N == 0) return 0;
   if (!dy) return -1001;
   if (!wT) return -1002;
   if (!dx) return -1009;
-  if (stride == 1 && halo_variant() &&
+  if (stride == 1 && !mask_y && !scale && halo_variant() &&
       ocpg_halo::conv3x3_halo((const __hip_bfloat16*)dy, (const __hip_bfloat16*)wT, nullptr, nullptr, 0, 1, N, H, W, Cout, Cin, (__hip_bfloat16*)dx,
                               (hipStream_t)stream)) {
     const hipError_t e = hipGetLastError();
@@ -367,10 +413,69 @@ extern "C" int ocpg_conv3x3_mfma_dgrad(const void* dy, const void* wT, int N, in
   const unsigned mt = (unsigned)((g.M + BM - 1) / BM);
   if (narrow_tiles(mt, Cin))
     conv3x3_mfma<true, 64><<<dim3(mt, (unsigned)((Cin + 63) / 64)), NT, 0, (hipStream_t)stream>>>(
-        (const __hip_bfloat16*)dy, (const __hip_bfloat16*)wT, nullptr, nullptr, 0, g, (__hip_bfloat16*)dx, nullptr);
+        (const __hip_bfloat16*)dy, (const __hip_bfloat16*)wT, scale, nullptr, 0, g, (__hip_bfloat16*)dx, nullptr, (const __hip_bfloat16*)mask_y);
   else
     conv3x3_mfma<true, 128><<<dim3(mt, (unsigned)((Cin + 127) / 128)), NT, 0, (hipStream_t)stream>>>(
-        (const __hip_bfloat16*)dy, (const __hip_bfloat16*)wT, nullptr, nullptr, 0, g, (__hip_bfloat16*)dx, nullptr);
+        (const __hip_bfloat16*)dy, (const __hip_bfloat16*)wT, scale, nullptr, 0, g, (__hip_bfloat16*)dx, nullptr, (const __hip_bfloat16*)mask_y);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+namespace {
+
+// out[m][c] = sum_z part[z][m][c] + bias[c]  (out_dt 0 fp32 / 1 bf16)
+__global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ part, const float* __restrict__ bias, int splits, long long MC, int Cout,
+                                                       void* __restrict__ out, int out_dt) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= MC) return;
+  float4 a = bias ? *reinterpret_cast<const float4*>(bias + i % Cout) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int z = 0; z < splits; ++z) {
+    const float4 v = *reinterpret_cast<const float4*>(part + (long long)z * MC + i);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  if (out_dt == 0) {
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + i) = a;
+  } else {
+    ushort4 o;
+    o.x = __bfloat16_as_ushort(__float2bfloat16(a.x)); o.y = __bfloat16_as_ushort(__float2bfloat16(a.y));
+    o.z = __bfloat16_as_ushort(__float2bfloat16(a.z)); o.w = __bfloat16_as_ushort(__float2bfloat16(a.w));
+    *reinterpret_cast<ushort4*>(reinterpret_cast<unsigned short*>(out) + i) = o;
+  }
+}
+
+}  // namespace
+
+// number of K ranges ocpg_conv3x3_mfma_fwd_splitk will use for this shape (a divisor of Cin / 64; 1 = the split does not pay: use the plain entry)
+extern "C" int ocpg_conv3x3_mfma_splits(int N, int H, int W, int Cin, int Cout, int stride) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (stride != 1 && stride != 2) || Cin % BK != 0 || Cout % 4 != 0) return 1;
+  const long long M = (long long)N * ((H - 1) / stride + 1) * ((W - 1) / stride + 1);
+  const long long tiles = ((M + BM - 1) / BM) * ((Cout + 63) / 64);
+  const int chunks = Cin / BK;
+  int best = 1;
+  for (int sgl = 1; sgl <= chunks; ++sgl)           // the largest split that keeps >= 2 chunks (18 K steps) per workgroup and <= ~1024 workgroups
+    if (chunks % sgl == 0 && chunks / sgl >= 2 && tiles * sgl <= 1024) best = sgl;
+  return tiles < 256 ? best : 1;
+}
+
+// part [splits][N*Ho*Wo][Cout] fp32 (scratch, fully written), y [N,Ho,Wo,Cout] = conv(x, w) + bias in out_dt (0 fp32 / 1 bf16);
+// cols as in ocpg_conv3x3_mfma_fwd_cols (may be NULL).  splits must be ocpg_conv3x3_mfma_splits(...) (> 1).
+extern "C" int ocpg_conv3x3_mfma_fwd_splitk(const void* x, const void* w, const float* bias, int N, int H, int W, int Cin, int Cout, int stride,
+                                            int splits, float* part, void* y, int out_dt, void* cols, void* stream) {
+  if (N < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return -1006;
+  if ((stride != 1 && stride != 2) || Cin % BK != 0 || Cout % 4 != 0 || splits < 1 || (Cin / BK) % splits != 0 || (out_dt != 0 && out_dt != 1)) return -2000;
+  if (N == 0) return 0;
+  if (!x) return -1001;
+  if (!w) return -1002;
+  if (!part) return -1011;
+  if (!y) return -1012;
+  ConvGeom g;
+  g.N = N; g.H = (H - 1) / stride + 1; g.W = (W - 1) / stride + 1; g.C = Cin; g.Hs = H; g.Ws = W; g.Cout = Cout; g.stride = stride;
+  g.M = (long long)N * g.H * g.W;
+  const unsigned mt = (unsigned)((g.M + BM - 1) / BM);
+  conv3x3_mfma<false, 64, true><<<dim3(mt, (unsigned)((Cout + 63) / 64), (unsigned)splits), NT, 0, (hipStream_t)stream>>>(
+      (const __hip_bfloat16*)x, (const __hip_bfloat16*)w, nullptr, nullptr, 0, g, reinterpret_cast<__hip_bfloat16*>(part), (__hip_bfloat16*)cols);
+  const long long MC = g.M * Cout;
+  k_splitk_reduce<<<(unsigned)((MC / 4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(part, bias, splits, MC, Cout, y, out_dt);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }

@@ -16,6 +16,7 @@
 namespace {
 
 constexpr int CHUNK = 2048;     // elements per workgroup: 256 lanes x 8
+constexpr int kBiasChunk = 256; // ... and per workgroup of a tensor whose slices are fp32 bias partials (bit 40 of its split count)
 
 template <typename T> __device__ __forceinline__ float to_f(T v);
 template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
@@ -48,12 +49,14 @@ __global__ __launch_bounds__(256) void multi_cast_sum(const long long* __restric
   if (ns >> 40) {             // bit 40: THIS tensor's slices are fp32 whatever S is (bias-gradient partials of ocpg_colsum_partials)
     // few elements (a bias), many slices: the whole workgroup walks the slices -- thread = (element, group of slices), consecutive
     // threads on consecutive elements (a thread per 8 elements left 32 lanes with 8 x ns dependent scalar loads each: the launch's tail)
+    // Such a tensor is cut into chunks of kBiasChunk = 256 elements (the host's chunk prefix agrees: amp_cache._BIAS_CHUNK): a 2 048-wide
+    // bias with 256 partial rows on ONE workgroup was a 1 ms serial tail of the launch (round 4, once the encoder FFNs deferred their sums).
     ns &= (1LL << 40) - 1;
     const float* sf = reinterpret_cast<const float*>(srcs[lo]);
-    __shared__ float accs[CHUNK];
-    const long long cb = (blk - chunk_prefix[lo]) * CHUNK;
-    const int cnt = (int)(count - cb < CHUNK ? count - cb : CHUNK);
-    int groups = CHUNK / cnt;                 // slices are dealt round-robin to the groups
+    __shared__ float accs[kBiasChunk];
+    const long long cb = (blk - chunk_prefix[lo]) * kBiasChunk;
+    const int cnt = (int)(count - cb < kBiasChunk ? count - cb : kBiasChunk);
+    int groups = kBiasChunk / cnt;            // slices are dealt round-robin to the groups
     if (groups > ns) groups = (int)ns;
     for (int w = threadIdx.x; w < cnt * groups; w += 256) {
       const int e = w % cnt, gk = w / cnt;
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(256) void multi_cast_sum(const long long* __restric
         a3 += sf[(k + 3LL * groups) * stride + cb + e];
       }
       for (; k < ns; k += groups) a0 += sf[k * stride + cb + e];
-      accs[w] = (a0 + a1) + (a2 + a3);        // slot (group, element): w = gk * cnt + e < CHUNK
+      accs[w] = (a0 + a1) + (a2 + a3);        // slot (group, element): w = gk * cnt + e < kBiasChunk
     }
     __syncthreads();
     for (int i = threadIdx.x; i < cnt; i += 256) {        // the groups are folded in a FIXED order: bit-reproducible run to run
@@ -81,7 +84,23 @@ __global__ __launch_bounds__(256) void multi_cast_sum(const long long* __restric
                     (ns == 1 || (stride * (long long)sizeof(S)) % 16 == 0);
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (wide) {
-    for (long long k = 0; k < ns; ++k) {
+    // four slices in flight (round 4: with the encoder FFNs' 34-slice partial sums finished here too, the one-load-at-a-time loop was the
+    // latency of ns dependent round trips per thread: 1 090 us for ~550 MB = 0.5 TB/s); slices are added in index order, one accumulator
+    long long k = 0;
+    for (; k + 4 <= ns; k += 4) {
+      S in[4][8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const S* sk = s + (k + u) * stride + base;
+        if constexpr (sizeof(S) == 4) { *reinterpret_cast<uint4*>(in[u]) = *reinterpret_cast<const uint4*>(sk); *reinterpret_cast<uint4*>(in[u] + 4) = *reinterpret_cast<const uint4*>(sk + 4); }
+        else *reinterpret_cast<uint4*>(in[u]) = *reinterpret_cast<const uint4*>(sk);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += to_f<S>(in[u][i]);
+    }
+    for (; k < ns; ++k) {
       S in[8];
       const S* sk = s + k * stride + base;
       if constexpr (sizeof(S) == 4) { *reinterpret_cast<uint4*>(in) = *reinterpret_cast<const uint4*>(sk); *reinterpret_cast<uint4*>(in + 4) = *reinterpret_cast<const uint4*>(sk + 4); }

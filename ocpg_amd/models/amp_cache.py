@@ -25,6 +25,7 @@ _ACTIVE = {}        # id(fp32 parameter) -> low-precision copy, valid inside one
 ENABLED = True      # A/B switch (tests compare against autocast's own per-op casts)
 GEMM_1X1 = os.environ.get("OCPG_GEMM_1X1", "1") != "0"     # A/B switch: 1x1 convs of channels-last maps as hipBLASLt GEMMs instead of MIOpen convolutions
 GEMM_3X3 = os.environ.get("OCPG_GEMM_3X3", "0") != "0"     # A/B switch: 3x3 convs of channels-last maps as HIP im2col + one hipBLASLt GEMM
+SPLITK_3X3 = os.environ.get("OCPG_SPLITK_3X3", "1") != "0"     # A/B switch: 3x3 convs with few output pixels and a long reduction through the split-K MFMA kernel (0 = MIOpen)
 SPLIT_K = os.environ.get("OCPG_SPLIT_K", "1") != "0"      # A/B switch: weight gradients over many rows as row-split batched GEMMs
 
 
@@ -169,6 +170,7 @@ def join_wgrad():
 
 _DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 _CHUNK = 2048
+_BIAS_CHUNK = 256
 
 
 def _dense(t):
@@ -224,10 +226,13 @@ class _CastPlan:
         n = len(idx)
         flat = torch.empty(self.total, dtype=torch.float32, device=self.device)
         base = flat.data_ptr()
-        prefix = [0]
-        for i in idx:
-            prefix.append(prefix[-1] + (self.numels[i] + _CHUNK - 1) // _CHUNK)
         parts = [_PARTIALS.pop(grads[i].data_ptr(), None) if _PARTIALS else None for i in idx]
+        prefix = [0]
+        for i, pr in zip(idx, parts):
+            # fp32 bias-gradient partials (flag bit 40: few elements, hundreds of slices) are folded by a workgroup per 256 elements
+            # (csrc/multi_cast.hip kBiasChunk): one workgroup per 2 048 took ~1 ms for the encoder FFNs' 2 048-wide biases
+            ch = _BIAS_CHUNK if (pr is not None and pr[0] >> 40) else _CHUNK
+            prefix.append(prefix[-1] + (self.numels[i] + ch - 1) // ch)
         for i, pr in zip(idx, parts):
             if pr is not None and pr[2] != self.numels[i]:
                 raise RuntimeError(f"deferred weight-gradient partials do not match the parameter they arrived for: parameter {i} of shape "
@@ -525,6 +530,12 @@ class Conv2d(nn.Conv2d):
                 x, w, b = x.to(dt), w.to(dt), None if b is None else b.to(dt)
             if x.dtype == w.dtype:
                 return Conv1x1AsGemm.apply(x, w, b)
+        elif SPLITK_3X3 and x.is_cuda and x.dim() == 4 and self.kernel_size == (3, 3) and torch.is_autocast_enabled("cuda") \
+                and torch.get_autocast_dtype("cuda") == torch.bfloat16 and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16:
+            from .ops.functions import conv_bn_func
+            if conv_bn_func.eligible3x3_splitk(x, self):       # few output pixels, long reduction: the neck's stride-2 level (csrc/conv3x3_mfma.hip, split-K)
+                return conv_bn_func.conv3x3_splitk(x, w, b, self.stride[0])
+            return self._conv_forward(x, w, b)
         elif GEMM_3X3 and x.is_cuda and conv_gemm_func.eligible(x, self):
             if torch.is_autocast_enabled("cuda"):
                 dt = torch.get_autocast_dtype("cuda")

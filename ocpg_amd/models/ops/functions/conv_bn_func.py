@@ -26,10 +26,17 @@ EPILOGUE = os.environ.get("OCPG_GEMM_EPILOGUE", "1") != "0"     # A/B switch: BN
 FWD_COLS = os.environ.get("OCPG_CONV3X3_FWD_COLS", "0") != "0"
 SKIP_GRAD_IN_GEMM = os.environ.get("OCPG_SKIP_GRAD_IN_GEMM", "1") != "0"
 _SKIP_TOKENS = {}           # data_ptr of a conv1 input -> token; cleared at the start of every backbone forward (reset_skip_tokens)
+# A/B switch (round 4): a bottleneck's conv1 -> bn1 -> ReLU output has ONE consumer, conv2.  conv2's input-gradient kernel (conv3x3_mfma<DGRAD>)
+# then also applies conv1's frozen-BN + ReLU backward in its epilogue (gz1 = gx * scale1 * [y1 > 0]) and conv1's backward skips its
+# bn_act_bwd launch (33 launches, ~0.5 ms per step at config #2).  conv1's forward leaves a token under its output's address, conv2's
+# forward picks it up when its input IS that tensor.
+PREMASK = os.environ.get("OCPG_PREMASK_DGRAD", "1") != "0"
+_PREMASK_TOKENS = {}        # data_ptr of a conv1 + bn1 + ReLU output -> token; cleared with the skip tokens
 
 
 def reset_skip_tokens():
     _SKIP_TOKENS.clear()
+    _PREMASK_TOKENS.clear()
 
 
 def _same_tensor(a, b):
@@ -37,6 +44,10 @@ def _same_tensor(a, b):
         return False
     return a is b or (a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.dtype == b.dtype and a.stride() == b.stride()
                       and a._version == b._version)
+
+
+def _tensor_key(t):
+    return (t.data_ptr(), tuple(t.shape), t.dtype, tuple(t.stride()), t._version)
 
 
 def _reduce_partials(part, w_is_cast_copy):
@@ -84,6 +95,13 @@ class Conv1x1BNAct(Function):
         ctx.meta = (bool(relu), skip is not None, splits)
         ctx.w_cast = is_cast_copy(w)
         ctx.give = ctx.take = None
+        ctx.premask = None
+        if PREMASK and relu and skip is None and x.dtype == torch.bfloat16 and ctx.needs_input_grad[1]:
+            # (the token identifies y by value, not by reference: ctx -> token -> y -> grad_fn -> ctx would be a cycle that keeps this
+            # forward's autograd graph alive until the garbage collector runs -- and a stale graph inside a later stream capture is the
+            # hipStreamEndCapture crash of DESIGN.md section 5)
+            ctx.premask = {"y": _tensor_key(y), "scale": scale, "gz": None}
+            _PREMASK_TOKENS[y.data_ptr()] = ctx.premask
         if SKIP_GRAD_IN_GEMM:
             if skip is not None:
                 tok = _SKIP_TOKENS.pop(skip.data_ptr(), None)
@@ -108,12 +126,17 @@ class Conv1x1BNAct(Function):
         if gy.dtype != y.dtype or not gy.is_contiguous(memory_format=_CL):
             gy = gy.to(y.dtype).contiguous(memory_format=_CL)
         need_x, need_w, need_skip = ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_skip and ctx.needs_input_grad[4]
-        gz = torch.empty_like(y)
-        gskip = torch.empty_like(y) if need_skip else None
-        rc = L.ocpg_bn_act_bwd(gy.data_ptr(), y.data_ptr(), scale.data_ptr(), gz.data_ptr(), None if gskip is None else gskip.data_ptr(),
-                               m, co, 1, int(relu), dt, st)
-        if rc:
-            check(rc, "ocpg_bn_act_bwd")
+        tok = ctx.premask
+        if tok is not None and tok["gz"] is not None and tok["gz"].data_ptr() == gy.data_ptr() and tok["gz"].shape == gy.shape:
+            gz, gskip = gy, None            # the consumer's input-gradient kernel already applied this layer's frozen-BN + ReLU backward
+            tok["gz"] = None
+        else:
+            gz = torch.empty_like(y)
+            gskip = torch.empty_like(y) if need_skip else None
+            rc = L.ocpg_bn_act_bwd(gy.data_ptr(), y.data_ptr(), scale.data_ptr(), gz.data_ptr(), None if gskip is None else gskip.data_ptr(),
+                                   m, co, 1, int(relu), dt, st)
+            if rc:
+                check(rc, "ocpg_bn_act_bwd")
         gx = gw = None
         if ctx.give is not None and need_skip:
             ctx.give["g"] = gskip                      # parked for conv1's input-gradient GEMM of this block (runs later in this backward)
@@ -277,6 +300,8 @@ class Conv3x3MfmaBNAct(Function):
         from ...amp_cache import is_cast_copy
         ctx.meta = (bool(relu), splits, stride)
         ctx.w_cast = is_cast_copy(w)
+        tok = _PREMASK_TOKENS.pop(x.data_ptr(), None) if PREMASK else None
+        ctx.premask = tok if (tok is not None and tok["y"] == _tensor_key(x) and ctx.needs_input_grad[0]) else None
         return y
 
     @staticmethod
@@ -297,7 +322,13 @@ class Conv3x3MfmaBNAct(Function):
         if ctx.needs_input_grad[0]:
             wt = w2.permute(3, 1, 2, 0).contiguous()               # [c,3,3,co]
             gx = torch.empty((n, c, h, wd), dtype=y.dtype, device=y.device, memory_format=_CL)
-            check(L.ocpg_conv3x3_mfma_dgrad(gz.data_ptr(), wt.data_ptr(), n, h, wd, c, co, stride, gx.data_ptr(), st), "ocpg_conv3x3_mfma_dgrad")
+            tok = ctx.premask
+            if tok is not None:     # x IS the layer in front's bn + ReLU output: its backward rides in this kernel's epilogue
+                check(L.ocpg_conv3x3_mfma_dgrad_masked(gz.data_ptr(), wt.data_ptr(), x.data_ptr(), tok["scale"].data_ptr(), n, h, wd, c, co, stride,
+                                                       gx.data_ptr(), st), "ocpg_conv3x3_mfma_dgrad_masked")
+                tok["gz"] = gx
+            else:
+                check(L.ocpg_conv3x3_mfma_dgrad(gz.data_ptr(), wt.data_ptr(), n, h, wd, c, co, stride, gx.data_ptr(), st), "ocpg_conv3x3_mfma_dgrad")
         if ctx.needs_input_grad[1]:
             from ...amp_cache import side_wgrad
             with side_wgrad(ctx.w_cast, gz, x) as sw:          # off the critical path: the weight-gradient stream (amp_cache.side_wgrad)
@@ -323,3 +354,74 @@ class Conv3x3MfmaBNAct(Function):
 
 def conv3x3_mfma_bn_act(x, w, scale, shift, relu, stride, splits):
     return Conv3x3MfmaBNAct.apply(x, w, scale, shift, relu, int(stride), splits)
+
+
+# ---- 3x3 conv (padding 1, stride 1|2) with bias, few output pixels and a long reduction: split-K on the matrix cores -------------------------
+def eligible3x3_splitk(x, conv):
+    """The neck's extra level (models/ocpg.py:119-123): bf16 channels-last map, 3x3 / padding 1 / stride 1|2, channel counts the kernel's
+    64-wide K step and output tile serve, and a GEMM so short in rows that the plain kernel would leave the chip empty
+    (ocpg_conv3x3_mfma_splits > 1)."""
+    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and conv.kernel_size == (3, 3) and conv.groups == 1
+            and conv.stride[0] == conv.stride[1] and conv.stride[0] in (1, 2) and conv.dilation == (1, 1) and conv.padding == (1, 1)
+            and conv.padding_mode == "zeros" and x.is_contiguous(memory_format=_CL) and x.shape[1] % 64 == 0 and conv.out_channels % 64 == 0):
+        return False
+    n, c, h, w = x.shape
+    return int(lib().ocpg_conv3x3_mfma_splits(n, h, w, c, conv.out_channels, conv.stride[0])) > 1
+
+
+class Conv3x3SplitK(Function):
+    """y = conv3x3(x, w) + b with K split over the grid (csrc/conv3x3_mfma.hip, SPLITK) + a summing pass.  The forward keeps the patch
+    matrix it gathered (the weight gradient's operand: gy^T cols, one hipBLASLt GEMM over the few rows); the input gradient is the MFMA
+    kernel on the channel-swapped weight (its GEMM has N*H*W rows: no split)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride):
+        n, c, h, wd = x.shape
+        co = w.shape[0]
+        ho, wo = (h - 1) // stride + 1, (wd - 1) // stride + 1
+        m = n * ho * wo
+        L = lib()
+        st = torch.cuda.current_stream().cuda_stream
+        w2 = w.permute(0, 2, 3, 1)                                   # [co,3,3,c]: a view when the weight is channels-last
+        if not w2.is_contiguous():
+            w2 = w2.contiguous()
+        splits = int(L.ocpg_conv3x3_mfma_splits(n, h, wd, c, co, stride))
+        part = torch.empty((splits, m, co), dtype=torch.float32, device=x.device)
+        y = torch.empty((n, co, ho, wo), dtype=x.dtype, device=x.device, memory_format=_CL)
+        need_w = ctx.needs_input_grad[1]
+        cols = torch.empty((m, 9 * c), dtype=x.dtype, device=x.device) if need_w else None
+        bf = None if b is None else b.float()
+        check(L.ocpg_conv3x3_mfma_fwd_splitk(x.data_ptr(), w2.data_ptr(), None if bf is None else bf.data_ptr(), n, h, wd, c, co, stride, splits,
+                                             part.data_ptr(), y.data_ptr(), 1, None if cols is None else cols.data_ptr(), st),
+              "ocpg_conv3x3_mfma_fwd_splitk")
+        ctx.save_for_backward(w2, cols if need_w else w2)
+        ctx.meta = (n, c, h, wd, ho, wo, stride, b is not None, need_w)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        w2, cols = ctx.saved_tensors
+        n, c, h, wd, ho, wo, stride, has_b, need_w = ctx.meta
+        co = w2.shape[0]
+        m, k = n * ho * wo, 9 * c
+        L = lib()
+        st = torch.cuda.current_stream().cuda_stream
+        if gy.dtype != torch.bfloat16 or not gy.is_contiguous(memory_format=_CL):
+            gy = gy.to(torch.bfloat16).contiguous(memory_format=_CL)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wt = w2.permute(3, 1, 2, 0).contiguous()               # [c,3,3,co]
+            gx = torch.empty((n, c, h, wd), dtype=gy.dtype, device=gy.device, memory_format=_CL)
+            check(L.ocpg_conv3x3_mfma_dgrad(gy.data_ptr(), wt.data_ptr(), n, h, wd, c, co, stride, gx.data_ptr(), st), "ocpg_conv3x3_mfma_dgrad")
+        if need_w and ctx.needs_input_grad[1]:
+            g2 = torch.empty((co, k), dtype=gy.dtype, device=gy.device)
+            check(L.ocpg_gemm(gy.data_ptr(), cols.data_ptr(), g2.data_ptr(), None, 1, 1, 1, 0, co, k, m, co, k, k, 1, 0, 0, 0, 1.0, 0.0, st), "ocpg_gemm")
+            gw = g2.view(co, 3, 3, c).permute(0, 3, 1, 2)          # channels-last strides of [co, c, 3, 3]
+        if has_b and ctx.needs_input_grad[2]:
+            gb = gy.permute(0, 2, 3, 1).reshape(m, co).float().sum(0).to(gy.dtype)
+        return gx, gw, gb, None
+
+
+def conv3x3_splitk(x, w, b, stride):
+    return Conv3x3SplitK.apply(x, w, b, int(stride))

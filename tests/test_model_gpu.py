@@ -138,8 +138,11 @@ def test_train_step_matches_reference_bench_kernels(golden, dev, fixture, tag, m
     res = model_checks.run_train_step(golden(fixture), tag, dev, rtol=1e-3, atol=1e-4)
     print(res)
     names = {n for n, rc in seen if rc == 0}
-    # the two dedicated self-attention backward kernels served the encoder (rc 0 = launched, not "-2000 unsupported")
-    assert "ocpg_msda_bwd_value_f32" in names and "ocpg_msda_bwd_locattn_f32" in names, names
+    # the dedicated self-attention kernels served the encoder (rc 0 = launched, not "-2000 unsupported"): with 4 levels x 4 points the fused
+    # front end (round 4) + the path-selecting grad_value entry, otherwise (config #1: 3 levels) the round-2 pair of backward entries
+    fused = {"ocpg_msda_fused_fwd_f32", "ocpg_msda_fused_bwd_qproj_f32", "ocpg_msda_bwd_value_sel_f32"}
+    assert fused <= names or {"ocpg_msda_bwd_value_f32", "ocpg_msda_bwd_locattn_f32"} <= names \
+        or {"ocpg_msda_bwd_value_sel_f32", "ocpg_msda_bwd_locattn_f32"} <= names, names
 
 
 @pytest.mark.parametrize("tag", ["nopad", "pad"])
@@ -653,6 +656,49 @@ def test_bottleneck_fused_conv_bn_act(dev, dtype, project):
             assert (a - b_).norm().item() <= 5e-2 * b_.norm().item()
 
 
+@pytest.mark.parametrize("cin,width,stride,project", [(512, 128, 1, False), (256, 128, 2, True)])
+def test_bottleneck_premasked_input_gradient(dev, cin, width, stride, project):
+    """Round 4: conv2's input-gradient kernel (conv3x3_mfma<DGRAD>) applies conv1's frozen-BN + ReLU backward in its epilogue and conv1's
+    backward skips its bn_act_bwd launch (conv_bn_func.PREMASK).  Same bottleneck, bf16 channels-last, with the fusion on and off: output
+    identical, every gradient equal up to the one bf16 rounding the fusion removes; with it ON the census shows one bn_act_bwd less."""
+    from ocpg_amd import _lib
+    from ocpg_amd.models import backbone
+    from ocpg_amd.models.ops.functions import conv_bn_func
+    torch.manual_seed(5)
+    blk = backbone.Bottleneck(cin, width, stride, 1, project).to(dev)
+    for m in blk.modules():
+        if isinstance(m, backbone.FrozenBatchNorm2d):
+            m.weight.uniform_(0.5, 1.5), m.bias.normal_(0, 0.1), m.running_mean.normal_(0, 0.1), m.running_var.uniform_(0.5, 1.5)
+        if isinstance(m, torch.nn.Conv2d):
+            m.to(memory_format=torch.channels_last)
+    blk = blk.to(torch.bfloat16)
+    x = torch.randn(2, cin, 14, 18, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    ho, wo = (14 - 1) // stride + 1, (18 - 1) // stride + 1
+    go = torch.randn(2, width * 4, ho, wo, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    res, counts = [], []
+    for on in (True, False):
+        old = conv_bn_func.PREMASK
+        conv_bn_func.PREMASK = on
+        try:
+            conv_bn_func.reset_skip_tokens()
+            xi = x.clone().requires_grad_(True)
+            blk.zero_grad()
+            calls = _lib.census(True)
+            y = blk(xi)
+            y.backward(go)
+            torch.cuda.synchronize()
+            counts.append(dict(calls))
+            _lib.census(False)
+            res.append([y.detach().float(), xi.grad.float()] + [p.grad.float() for p in blk.parameters()])
+        finally:
+            conv_bn_func.PREMASK = old
+    assert counts[0].get("ocpg_conv3x3_mfma_dgrad_masked", 0) == 1 and counts[1].get("ocpg_conv3x3_mfma_dgrad_masked", 0) == 0, counts
+    assert counts[0].get("ocpg_bn_act_bwd", 0) == counts[1].get("ocpg_bn_act_bwd", 0) - 1, counts
+    assert torch.equal(res[0][0], res[1][0])
+    for a, b_ in zip(res[0][1:], res[1][1:]):
+        assert (a - b_).norm().item() <= 1e-2 * b_.norm().item(), ((a - b_).norm().item(), b_.norm().item())
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("stride,dil,bias,hw", [(1, 1, False, (13, 17)), (2, 1, True, (13, 16)), (2, 1, False, (12, 17)), (1, 2, True, (9, 11))])
 def test_conv3x3_as_im2col_gemm(dev, dtype, stride, dil, bias, hw):
@@ -1023,6 +1069,33 @@ def test_conv3x3_mfma_kernel(dev, n, c, co, h, w, stride, relu):
     assert (y.float() - yr).abs().max().item() <= 2e-2 * yr.abs().max().item() + 1e-3
 
 
+@pytest.mark.parametrize("n,c,co,h,w,stride", [(10, 2048, 256, 12, 20, 2), (2, 512, 128, 7, 9, 1), (1, 256, 64, 5, 5, 2)])
+def test_conv3x3_splitk_kernel(dev, n, c, co, h, w, stride):
+    """csrc/conv3x3_mfma.hip SPLITK (round 4: the neck's stride-2 level input_proj[3], models/ocpg.py:119-123, off MIOpen): K split over
+    the grid, fp32 partial tiles, a summing pass with the bias; input gradient by the MFMA kernel, weight gradient from the patch matrix the
+    forward wrote.  Against F.conv2d in fp32 on the same bf16-rounded operands: the config-#2 shape, a stride-1 shape with ragged tiles
+    and a tiny one."""
+    from ocpg_amd.models.ops.functions import conv_bn_func as f
+    from ocpg_amd import _lib
+    assert int(_lib.lib().ocpg_conv3x3_mfma_splits(n, h, w, c, co, stride)) > 1
+    g = torch.Generator(device="cpu").manual_seed(n * 100 + c + h)
+    x = torch.randn(n, c, h, w, generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(co, c, 3, 3, generator=g) * (2.0 / (9 * c)) ** 0.5).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    b = (torch.randn(co, generator=g) * 0.1).to(dev).to(torch.bfloat16)
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    go = torch.randn(n, co, ho, wo, generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    xi, wi, bi = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = f.conv3x3_splitk(xi, wi, bi, stride)
+    assert y.shape == (n, co, ho, wo) and y.is_contiguous(memory_format=torch.channels_last)
+    gx, gw, gb = torch.autograd.grad(y, (xi, wi, bi), go)
+    xr, wr, br = x.float().requires_grad_(True), wt.float().requires_grad_(True), b.float().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, wr, br, stride, 1)
+    gxr, gwr, gbr = torch.autograd.grad(yr, (xr, wr, br), go.float())
+    rel = lambda a, b_: float((a.float() - b_).norm() / (b_.norm() + 1e-20))      # noqa: E731
+    assert rel(y, yr) <= 6e-3, rel(y, yr)                                     # bf16 output rounding
+    assert rel(gx, gxr) <= 1.5e-2 and rel(gw, gwr) <= 1.5e-2 and rel(gb, gbr) <= 1.5e-2, (rel(gx, gxr), rel(gw, gwr), rel(gb, gbr))
+
+
 @pytest.mark.timeout(900)
 def test_full_size_step_vs_oracle(dev):
     """BASELINE config #2 at FULL size (ResNet-101, 4+4 layers, 5 queries, one clip of 5 x 384 x 640, fp32, dropout off): the product's
@@ -1311,3 +1384,38 @@ def test_colsum_partials_equals_sum(dev, dtype, shape):
     got = part.double().sum(0)
     assert torch.isfinite(part).all()
     assert (got - want).abs().max().item() <= 1e-5 * (x.double().abs().sum(0).max().item() + 1.0)
+
+
+def test_deferred_partial_sums_finish_inside_the_gradient_cast(dev):
+    """amp_cache.defer_sum: the row-split weight-gradient partials [S, Co, K] and the fp32 column-sum partials behind bias gradients of
+    single-use layers are finished by the ONE launch that casts all gradients to fp32 (csrc/multi_cast.hip: multi_cast_sum; bias partials in
+    256-element chunks since round 4).  A 256 -> 2048 -> 256 token MLP over 16 384 rows (34-way and 2 048-wide cases of the encoder FFN in
+    miniature) under bf16 autocast, with the deferral on and off: identical fp32 gradients up to the summation order."""
+    from ocpg_amd.models import amp_cache
+    torch.manual_seed(2)
+    net = torch.nn.Sequential(amp_cache.Linear(256, 2048), torch.nn.ReLU(), amp_cache.Linear(2048, 256)).to(dev)
+    amp_cache.mark_single_use(net[0], net[2])
+    x = torch.randn(16384, 256, device=dev)
+    go = torch.randn(16384, 256, device=dev)
+    res = []
+    for on in (True, False):
+        old = amp_cache.DEFER_SUM
+        amp_cache.DEFER_SUM = on
+        try:
+            net.zero_grad(set_to_none=True)
+            calls = __import__("ocpg_amd._lib", fromlist=["census"]).census(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16), amp_cache.scope(net):
+                y = net(x)
+            (y.float() * go).sum().backward()
+            torch.cuda.synchronize()
+            seen = dict(calls)
+            __import__("ocpg_amd._lib", fromlist=["census"]).census(False)
+            assert not amp_cache._PARTIALS
+            assert (seen.get("ocpg_multi_cast_sum", 0) >= 1) == on, seen
+            res.append([p.grad.clone() for p in net.parameters()])
+            assert all(g.dtype == torch.float32 for g in res[-1])
+        finally:
+            amp_cache.DEFER_SUM = old
+    for a, b_ in zip(*res):
+        assert (a - b_).abs().max().item() <= 2e-2 * b_.abs().max().item() + 1e-6, ((a - b_).abs().max().item(), b_.abs().max().item())
+        assert (a - b_).norm().item() <= 4e-3 * b_.norm().item()
