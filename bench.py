@@ -127,8 +127,13 @@ class EagerStep:
         self.optimizer.zero_grad(set_to_none=True)
         loss = forward_backward(self.ddp_model, self.criterion, self.make_samples(), self.text, self.targets, self.amp_dtype,
                                 scaler=self.scaler)
-        if self.scaler is None and hasattr(self.optimizer, "step_clip"):
-            self.grad_norm = self.optimizer.step_clip(self.args.clip_max_norm)     # norm + clip + AdamW: three launches
+        if hasattr(self.optimizer, "step_clip"):
+            if self.scaler is None:
+                self.grad_norm = self.optimizer.step_clip(self.args.clip_max_norm)     # norm + clip + AdamW: three launches
+            else:                                                                      # + unscale and the skip-on-overflow, on the device
+                self.scaler.step(self.optimizer, max_norm=self.args.clip_max_norm)
+                self.scaler.update()
+                self.grad_norm = self.optimizer.grad_norm
             return loss
         if self.scaler is not None:
             self.scaler.unscale_(self.optimizer)
@@ -291,22 +296,43 @@ class GraphStep:
         if not ok:
             raise RuntimeError(f"graph replay disagrees with eager on the same dropout masks: {loss} vs {ref} (tolerance {tol}); other masks: {eager_loss}")
 
+    def _phase(self, name):
+        """OCPG_STEP_PHASES=1 (diagnostic): host wall time per phase of a step with a device sync at every boundary -> self.phases."""
+        if not self.__dict__.setdefault("_ph_on", os.environ.get("OCPG_STEP_PHASES") == "1"):
+            return
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        ph = self.__dict__.setdefault("phases", {})
+        if self.__dict__.get("_ph_last") is not None and name is not None:
+            ph[name] = ph.get(name, 0.0) + now - self._ph_last
+        self._ph_last = now
+
     def __call__(self):
+        self._phase(None)
         s = self.make_samples()
         assert getattr(s.mask, "_ocpg_key", None) == self.mask_key, "the captured step assumes the valid extents it was captured with"
         self.x.copy_(s.tensors), self.mask.copy_(s.mask)
         self.num_boxes.copy_(self.criterion.global_num_boxes(self.targets, self.x.device))
+        self._phase("inputs")
         if self.captions is not None:
             for dst, src in zip(self.text, self._encode_text()):
                 dst.copy_(src)
+        self._phase("text encoder (eager)")
         if self.fence:
             torch.cuda.synchronize()
         self.replay_and_reduce()
+        self._phase("graph replay")
         if self.fence:
             torch.cuda.synchronize()
         self.criterion.iter_device += self.calls_per_fwd
-        if self.scaler is None and hasattr(self.optimizer, "step_clip"):
-            self.grad_norm = self.optimizer.step_clip(self.args.clip_max_norm)     # norm + clip + AdamW: three launches
+        if hasattr(self.optimizer, "step_clip"):
+            if self.scaler is None:
+                self.grad_norm = self.optimizer.step_clip(self.args.clip_max_norm)     # norm + clip + AdamW: three launches
+            else:                                                                      # + unscale and the skip-on-overflow, on the device
+                self.scaler.step(self.optimizer, max_norm=self.args.clip_max_norm)
+                self.scaler.update()
+                self.grad_norm = self.optimizer.grad_norm
+            self._phase("clip + step")
             return self.loss
         if self.scaler is not None:
             self.scaler.unscale_(self.optimizer)
@@ -317,6 +343,7 @@ class GraphStep:
             self.scaler.update()
         else:
             self.optimizer.step()
+        self._phase("unscale + clip + step + update")
         return self.loss
 
 
@@ -916,6 +943,8 @@ def main():
     }
     if fallback_note:
         line["config"]["launch_fallback"] = fallback_note
+    if getattr(step, "phases", None):
+        line["step_phases_ms"] = {k: v / (a.steps + a.warmup + 3) * 1e3 for k, v in step.phases.items()}
     if mode != "eager":
         line["hipgraph"] = {"memset_nodes_replaced_by_kernel_nodes": step.memset_nodes_replaced,
                             "checked_against_eager": getattr(step, "check_result", True), "graphs": len(step.graphs)}

@@ -339,6 +339,18 @@ int ocpg_grad_norm_clip(const long long* grads, const long long* numels, const l
 int ocpg_adamw_step(const long long* params, const long long* grads, const long long* exp_avg, const long long* exp_avg_sq,
                     const long long* numels, const long long* chunk_prefix, const float* lr, const float* weight_decay, int n,
                     long long total_chunks, const float* norm_and_coef, double beta1, double beta2, double eps, long long step, void* stream);
+/* The same under torch.amp.GradScaler (engine.py:98-106, --amp with fp16: scaler.unscale_ + clip_grad_norm_ + scaler.step, whose
+ * found_inf.item() stalls the host every step): the gradients still carry `grad_scale[0]` (device scalar; NULL: already unscaled).
+ * amp_state (fp32[6], device): [0] norm of the unscaled gradients, [1] coefficient applied to the scaled gradients = clip / scale,
+ * [2] 1 when the step is skipped (non-finite norm, or found_inf[0] != 0 when found_inf is given), [3] number of steps TAKEN (in/out:
+ * skipped steps do not advance the bias corrections, as GradScaler skips optimizer.step() as a whole), [4], [5] bias corrections of
+ * that count.  ocpg_adamw_step_amp returns without touching p / exp_avg / exp_avg_sq when [2] is set. */
+int ocpg_grad_norm_clip_amp(const long long* grads, const long long* numels, const long long* chunk_prefix, int n, long long total_chunks,
+                            float max_norm, float* partials, const float* grad_scale, const float* found_inf, double beta1, double beta2,
+                            float* amp_state, void* stream);
+int ocpg_adamw_step_amp(const long long* params, const long long* grads, const long long* exp_avg, const long long* exp_avg_sq,
+                        const long long* numels, const long long* chunk_prefix, const float* lr, const float* weight_decay, int n,
+                        long long total_chunks, const float* amp_state, double beta1, double beta2, double eps, void* stream);
 
 /* Classification (sigmoid focal, alpha < 0 disables the alpha weighting) + L1 + GIoU losses of the matched queries, all layers
  * per launch -- replaces SetCriterion.loss_labels / loss_boxes (models/criterion.py:46-107; sigmoid_focal_loss

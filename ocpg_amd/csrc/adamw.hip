@@ -65,6 +65,39 @@ __global__ __launch_bounds__(1024) void norm_finish(const float* __restrict__ pa
   }
 }
 
+// The same under torch.amp.GradScaler (engine.py:98-106 with --amp on fp16): the gradients are still multiplied by `scale`.  One thread
+// folds 1 / scale into the clip coefficient, decides whether the step is skipped (a non-finite norm -- some gradient overflowed -- or the
+// scaler's own found_inf flag), advances the DEVICE step counter only for steps that are taken (GradScaler skips optimizer.step() as a
+// whole, so the bias corrections must not see skipped steps) and leaves the bias corrections of that count for adamw_apply.  Nothing
+// here needs the host to know whether the step was taken: no .item() sync.
+//   st[0] = norm of the UNSCALED gradients before clipping, st[1] = coefficient for the scaled gradients, st[2] = 1 when skipped,
+//   st[3] = steps taken (in/out), st[4] = 1 - beta1^step, st[5] = 1 / sqrt(1 - beta2^step)
+__global__ __launch_bounds__(1024) void norm_finish_amp(const float* __restrict__ part, long long n, float max_norm, const float* __restrict__ grad_scale,
+                                                        const float* __restrict__ found_inf, double beta1, double beta2, float* __restrict__ st) {
+  double s = 0.0;
+  for (long long i = threadIdx.x; i < n; i += 1024) s += (double)part[i];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  __shared__ double ws[16];
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < 16; ++i) t += ws[i];
+    const float scaled = (float)sqrt(t);
+    const float inv = grad_scale ? 1.f / grad_scale[0] : 1.f;
+    const float norm = scaled * inv;
+    const bool skip = !(fabsf(scaled) <= 3.402823466e38f) || (found_inf && found_inf[0] != 0.f);
+    const float coef = max_norm / (norm + 1e-6f);
+    st[0] = norm;
+    st[1] = (max_norm > 0.f ? (coef < 1.f ? coef : 1.f) : 1.f) * inv;
+    st[2] = skip ? 1.f : 0.f;
+    const float step = st[3] + (skip ? 0.f : 1.f);
+    st[3] = step;
+    st[4] = (float)(1.0 - pow(beta1, (double)step));
+    st[5] = (float)(1.0 / sqrt(1.0 - pow(beta2, (double)step)));
+  }
+}
+
 constexpr int GROUP = 4;        // table chunks per workgroup: 4 x (4 reads + 3 writes) of 32 B per lane in flight
 
 __global__ __launch_bounds__(256) void adamw_apply(const long long* __restrict__ params, const long long* __restrict__ grads,
@@ -72,9 +105,13 @@ __global__ __launch_bounds__(256) void adamw_apply(const long long* __restrict__
                                                    const long long* __restrict__ numels, const long long* __restrict__ chunk_prefix,
                                                    const float* __restrict__ lr, const float* __restrict__ wd, int n, long long total_chunks,
                                                    const float* __restrict__ clip, float om_beta1, float beta2, float om_beta2, float eps, float bc1,
-                                                   float rsqrt_bc2) {
+                                                   float rsqrt_bc2, int amp) {
   const long long blk0 = (long long)blockIdx.x * GROUP;
   const float coef = clip ? clip[1] : 1.f;
+  if (amp) {                                // (norm_finish_amp's verdict and bias corrections; uniform over the grid)
+    if (clip[2] != 0.f) return;
+    bc1 = clip[4], rsqrt_bc2 = clip[5];
+  }
   int t = find_tensor(chunk_prefix, n, blk0);
   float pv[GROUP][8], gv[GROUP][8], mv[GROUP][8], vv[GROUP][8];
   float* pp[GROUP];
@@ -184,7 +221,35 @@ int ocpg_adamw_step(const long long* params, const long long* grads, const long 
   const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
   adamw_apply<<<(unsigned)((total_chunks + GROUP - 1) / GROUP), 256, 0, (hipStream_t)stream>>>(params, grads, exp_avg, exp_avg_sq, numels, chunk_prefix, lr,
                                                                                               weight_decay, n, total_chunks, norm_and_coef, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)bc1,
-                                                                       (float)(1.0 / sqrt(bc2)));
+                                                                       (float)(1.0 / sqrt(bc2)), 0);
+  return status();
+}
+
+int ocpg_grad_norm_clip_amp(const long long* grads, const long long* numels, const long long* chunk_prefix, int n, long long total_chunks,
+                            float max_norm, float* partials, const float* grad_scale, const float* found_inf, double beta1, double beta2,
+                            float* amp_state, void* stream) {
+  if (n < 0 || total_chunks < 0) return -1004;
+  if (!amp_state) return -1008;
+  hipStream_t st = (hipStream_t)stream;
+  if (n > 0 && total_chunks > 0) {
+    if (!grads || !numels || !chunk_prefix || !partials) return -1001;
+    if (total_chunks > 2147483647LL) return -1005;
+    sqnorm_partials<<<(unsigned)total_chunks, 256, 0, st>>>(grads, numels, chunk_prefix, n, partials);
+  }
+  norm_finish_amp<<<1, 1024, 0, st>>>(partials, n > 0 ? total_chunks : 0, max_norm, grad_scale, found_inf, beta1, beta2, amp_state);
+  return status();
+}
+
+int ocpg_adamw_step_amp(const long long* params, const long long* grads, const long long* exp_avg, const long long* exp_avg_sq,
+                        const long long* numels, const long long* chunk_prefix, const float* lr, const float* weight_decay, int n,
+                        long long total_chunks, const float* amp_state, double beta1, double beta2, double eps, void* stream) {
+  if (n < 0 || total_chunks < 0) return -1009;
+  if (n == 0 || total_chunks == 0) return 0;
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !numels || !chunk_prefix || !lr || !weight_decay || !amp_state) return -1001;
+  if (total_chunks > 2147483647LL) return -1010;
+  adamw_apply<<<(unsigned)((total_chunks + GROUP - 1) / GROUP), 256, 0, (hipStream_t)stream>>>(params, grads, exp_avg, exp_avg_sq, numels, chunk_prefix, lr,
+                                                                                              weight_decay, n, total_chunks, amp_state, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, 1.f,
+                                                                                              1.f, 1);
   return status();
 }
 

@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "win_attn_mfma.h"
 
 namespace {
@@ -77,32 +79,47 @@ __device__ __forceinline__ void stage_out_rows(E* dst, const T* t_bw, int N, int
   }
 }
 
-// transposed copy: src rows [N][32] (qkv `which`, or an out-like tensor when which < 0) -> LDS [32][Np + 8] (d major, keys contiguous)
-template <typename T, typename E>
-__device__ __forceinline__ void stage_transposed(E* dst, const T* base, int N, int Np, int H, int h, int which, float mul) {
-  typedef MM<T> M;
-  const int ld = Np + 8;
-  for (int e = threadIdx.x; e < Np * 4; e += blockDim.x) {
-    const int j = e >> 2, seg = e & 3;
-    typename M::v8 v = {};
-    if (j < N) {
-      const T* p = which >= 0 ? base + (((long long)j * 3 + which) * H + h) * HD + seg * 8 : base + (long long)j * H * HD + h * HD + seg * 8;
-      v = *reinterpret_cast<const typename M::v8*>(p);
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) dst[(seg * 8 + u) * ld + j] = mul == 1.f ? v[u] : M::bits(M::val(v[u]) * mul);
-  }
+// A operand of the second-type products (O^T += V^T P^T, dq^T += K^T dS^T, dv^T += dO^T P, dk^T += Q^T dS): row d = lane & 31 of the
+// TRANSPOSE of a row-major LDS tile [key][KROW], at the 8 positions sigma_s(h, .) = 16 s + 4 h + {0..3, 8..11} of the 32-wide tile at
+// t0.  Round 4: read straight from the row-major tile with gfx950's transposing LDS read (ds_read_b64_tr_b16: per 16-lane group a
+// 4-row x 16-column block, delivered column-major: lane i of the group gets column i of the 4 rows; lane 4q + p supplies row q,
+// columns 4p..4p+3) -- the separate [32][Np + 8] transposed copies are gone, and with them a third of the LDS of the backward kernels:
+// two workgroups per CU at N = 392 instead of one (one wave per SIMD had every latency exposed).
+__device__ __forceinline__ MM<__hip_bfloat16>::v4 tr_read4(const short* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) MM<__hip_bfloat16>::v4*)p);
 }
-
-// A operand of the second-type products: row `d` of a transposed LDS tile, the 8 positions sigma_s(h, .) of the 32-wide tile at `t0`
+__device__ __forceinline__ MM<__half>::v4 tr_read4(const _Float16* p) {
+  const MM<__hip_bfloat16>::v4 raw = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) MM<__hip_bfloat16>::v4*)p);
+  MM<__half>::v4 v;
+  __builtin_memcpy(&v, &raw, sizeof(v));          // the same 64 bits, typed as halves
+  return v;
+}
 template <typename T, typename E>
-__device__ __forceinline__ typename MM<T>::v8 sigma_frag(const E* tile_t, int ld, int d, int t0, int s, int h) {
+__device__ __forceinline__ typename MM<T>::v8 tr_frag(const E* tile, int t0, int s, int lane) {
   typedef MM<T> M;
-  const E* p = tile_t + d * ld + t0 + 16 * s + 4 * h;
-  const typename M::v4 lo = *reinterpret_cast<const typename M::v4*>(p), hi = *reinterpret_cast<const typename M::v4*>(p + 8);
+  const int g = lane >> 4, li = lane & 15;
+  const E* p = tile + (t0 + 16 * s + 4 * (g >> 1) + (li >> 2)) * KROW + 16 * (g & 1) + 4 * (li & 3);
+  const typename M::v4 lo = tr_read4(p), hi = tr_read4(p + 8 * KROW);
   typename M::v8 a;
   a[0] = lo[0]; a[1] = lo[1]; a[2] = lo[2]; a[3] = lo[3]; a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
   return a;
+}
+
+constexpr float kLog2e = 1.4426950408889634f;
+// exp(x - m) as ONE fused multiply-add and the hardware exp2: x, m natural-log units, mL = m * log2(e)
+__device__ __forceinline__ float exp_sub(float x, float mL) { return __builtin_amdgcn_exp2f(__builtin_fmaf(x, kLog2e, -mL)); }
+
+// region ids of this window -> LDS; returns (workgroup-uniform) whether the window spans more than one shift region: only then the
+// -100 mask exists at all (interior windows of a shifted block and every window of an unshifted block skip its 3 ops + 1 LDS read per score)
+__device__ __forceinline__ bool stage_regions(int* reg_s, const int* reg_w, int N, int Np) {
+  int differs = 0;
+  const int r0 = reg_w ? reg_w[0] : 0;
+  for (int j = threadIdx.x; j < Np; j += blockDim.x) {
+    const int v = (reg_w && j < N) ? reg_w[j] : r0;
+    reg_s[j] = v;
+    differs |= v != r0;
+  }
+  return __syncthreads_or(differs) != 0;
 }
 
 template <typename T>
@@ -112,18 +129,15 @@ __global__ __launch_bounds__(256) void k_fwd(const T* __restrict__ qkv, const fl
   typedef decltype(M::bits(0.f)) E;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   E* Ks = reinterpret_cast<E*>(smem);                       // [Np][KROW]
-  E* Vt = Ks + (size_t)Np * KROW;                           // [32][Np + 8]
-  int* reg_s = reinterpret_cast<int*>(Vt + (size_t)HD * (Np + 8));
+  E* Vs = Ks + (size_t)Np * KROW;                           // [Np][KROW] (read transposed: tr_frag)
+  int* reg_s = reinterpret_cast<int*>(Vs + (size_t)Np * KROW);
   const int bw = blockIdx.x / H, hh = blockIdx.x % H;
   const T* base = qkv + (long long)bw * N * 3 * H * HD;
   stage_rows<T, E>(Ks, base, N, Np, H, hh, 1, 1.f);
-  stage_transposed<T, E>(Vt, base, N, Np, H, hh, 2, 1.f);
-  const int* reg_w = region ? region + (long long)(bw % NW) * N : nullptr;
-  for (int j = threadIdx.x; j < Np; j += blockDim.x) reg_s[j] = (reg_w && j < N) ? reg_w[j] : 0;
-  __syncthreads();
+  stage_rows<T, E>(Vs, base, N, Np, H, hh, 2, 1.f);
+  const bool shifted = stage_regions(reg_s, region ? region + (long long)(bw % NW) * N : nullptr, N, Np);     // (ends with a barrier)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const float* bT = biasT + (long long)hh * N * N;
-  const int ldv = Np + 8;
   for (int qt = wave; qt < Np / 32; qt += 4) {
     const int q = qt * 32 + r;
     const bool qok = q < N;
@@ -163,30 +177,33 @@ __global__ __launch_bounds__(256) void k_fwd(const T* __restrict__ qkv, const fl
 #pragma unroll
       for (int s = 0; s < 2; ++s)
         sa = M::mfma(*reinterpret_cast<const typename M::v8*>(Ks + (kt + r) * KROW + 16 * s + 8 * h), qf[s], sa);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sa[i] += bc[i];
+      if (shifted) {                     // (workgroup-uniform) only windows that span two shift regions carry the -100 mask
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sa[i] += (reg_s[kt + key_of(i, h)] != rq) ? -100.f : 0.f;
+      }
+      if (kt + 32 > N) {                 // (uniform) only the last key tile holds padding keys
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sa[i] = kt + key_of(i, h) < N ? sa[i] : -INFINITY;
+      }
       float mx = -INFINITY;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int key = kt + key_of(i, h);
-        float v = sa[i] + bc[i];
-        v += (reg_s[key] != rq) ? -100.f : 0.f;          // reg_s is all zero without a shift
-        v = key < N ? v : -INFINITY;
-        sa[i] = v;
-        mx = fmaxf(mx, v);
-      }
+      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sa[i]);
       mx = fmaxf(mx, xhalf(mx));
-      const float mn = fmaxf(m, mx);
-      const float corr = __expf(m - mn);
+      const float mn = fmaxf(m, mx), mnL = mn * kLog2e;
+      const float corr = exp_sub(m, mnL);
       l *= corr;
       typename M::v8 pf[2];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         o[i] *= corr;
-        const float p = __expf(sa[i] - mn);
+        const float p = exp_sub(sa[i], mnL);
         l += p;
         pf[i >> 3][i & 7] = M::bits(p);
       }
 #pragma unroll
-      for (int s = 0; s < 2; ++s) o = M::mfma(sigma_frag<T, E>(Vt, ldv, r, kt, s, h), pf[s], o);
+      for (int s = 0; s < 2; ++s) o = M::mfma(tr_frag<T, E>(Vs, kt, s, lane), pf[s], o);
       m = mn;
     }
     l += xhalf(l);
@@ -207,7 +224,7 @@ __global__ __launch_bounds__(256) void k_fwd(const T* __restrict__ qkv, const fl
 
 // ---- backward, pass 1: a wave owns a 32-query tile (transposed layout as in the forward).
 //   D_q = dO_q . O_q;   P^T = exp(S^T + bias + mask - lse_q);   dP^T[key, q] = V[key, :] . dO[q, :];   dS^T = P^T (dP^T - D_q)
-//   dq^T[d, q] = scale * sum_key K^T[d, key] dS^T[key, q]      (A = K^T from LDS in sigma order, B = the lane's own dS registers)
+//   dq^T[d, q] = scale * sum_key K^T[d, key] dS^T[key, q]      (A = K^T read transposed from the row-major K tile, B = the lane's own dS registers)
 //   dS^T is also written (storage dtype, [BW, H, N(key), N(q)]) for the bias gradient: summing that tensor over the windows costs
 //   2 x 232 MB of streaming traffic at Swin-T stage 1, the per-element float atomics of the vector-ALU kernel 464 MB of atomic adds.
 template <typename T>
@@ -218,21 +235,16 @@ __global__ __launch_bounds__(256) void k_bwd_q(const T* __restrict__ qkv, const 
   typedef MM<T> M;
   typedef decltype(M::bits(0.f)) E;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  E* Ks = reinterpret_cast<E*>(smem);                       // [Np][KROW]
+  E* Ks = reinterpret_cast<E*>(smem);                       // [Np][KROW] (row reads for S^T, transposed reads for dq^T)
   E* Vs = Ks + (size_t)Np * KROW;                           // [Np][KROW]
-  E* Kt = Vs + (size_t)Np * KROW;                           // [32][Np + 8]
-  int* reg_s = reinterpret_cast<int*>(Kt + (size_t)HD * (Np + 8));
+  int* reg_s = reinterpret_cast<int*>(Vs + (size_t)Np * KROW);
   const int bw = blockIdx.x / H, hh = blockIdx.x % H;
   const T* base = qkv + (long long)bw * N * 3 * H * HD;
   stage_rows<T, E>(Ks, base, N, Np, H, hh, 1, 1.f);
   stage_rows<T, E>(Vs, base, N, Np, H, hh, 2, 1.f);
-  stage_transposed<T, E>(Kt, base, N, Np, H, hh, 1, 1.f);
-  const int* reg_w = region ? region + (long long)(bw % NW) * N : nullptr;
-  for (int j = threadIdx.x; j < Np; j += blockDim.x) reg_s[j] = (reg_w && j < N) ? reg_w[j] : 0;
-  __syncthreads();
+  const bool shifted = stage_regions(reg_s, region ? region + (long long)(bw % NW) * N : nullptr, N, Np);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const float* bT = biasT + (long long)hh * N * N;
-  const int ldt = Np + 8;
   E* dSw = dS ? reinterpret_cast<E*>(dS) + ((long long)bw * H + hh) * N * N : nullptr;
   for (int qt = wave; qt < Np / 32; qt += 4) {
     const int q = qt * 32 + r;
@@ -254,7 +266,7 @@ __global__ __launch_bounds__(256) void k_bwd_q(const T* __restrict__ qkv, const 
       gf[s] = g;
     }
     Dq += xhalf(Dq);
-    const float lq = lse[((long long)bw * H + hh) * N + qc];
+    const float lqL = lse[((long long)bw * H + hh) * N + qc] * kLog2e;
     const int rq = reg_s[qc];
     f32x16 dq;
 #pragma unroll
@@ -278,20 +290,29 @@ __global__ __launch_bounds__(256) void k_bwd_q(const T* __restrict__ qkv, const 
         sa = M::mfma(*reinterpret_cast<const typename M::v8*>(Ks + (kt + r) * KROW + 16 * s + 8 * h), qf[s], sa);
         dp = M::mfma(*reinterpret_cast<const typename M::v8*>(Vs + (kt + r) * KROW + 16 * s + 8 * h), gf[s], dp);
       }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sa[i] += bc[i];
+      if (shifted) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sa[i] += (reg_s[kt + key_of(i, h)] != rq) ? -100.f : 0.f;
+      }
+      if (kt + 32 > N) {                 // padding keys: P = exp2(-inf) = 0
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sa[i] = kt + key_of(i, h) < N ? sa[i] : -INFINITY;
+      }
       typename M::v8 df[2];
+      const bool tail = kt + 32 > N;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int key = kt + key_of(i, h);
-        float v = sa[i] + bc[i];
-        v += (reg_s[key] != rq) ? -100.f : 0.f;
-        const float p = key < N ? __expf(v - lq) : 0.f;
+        const float p = exp_sub(sa[i], lqL);
         const float ds = p * (dp[i] - Dq);
         const E dsb = M::bits(ds);
         df[i >> 3][i & 7] = dsb;
-        if (dSw && qok && key < N) dSw[(long long)key * N + q] = dsb;       // lanes = consecutive q: 64 contiguous bytes per key
+        if (dSw && qok && (!tail || key < N)) dSw[(long long)key * N + q] = dsb;       // lanes = consecutive q: 64 contiguous bytes per key
       }
 #pragma unroll
-      for (int s = 0; s < 2; ++s) dq = M::mfma(sigma_frag<T, E>(Kt, ldt, r, kt, s, h), df[s], dq);
+      for (int s = 0; s < 2; ++s) dq = M::mfma(tr_frag<T, E>(Ks, kt, s, lane), df[s], dq);
     }
     if (qok) {
       T* drow = dqkv + (((long long)(bw * (long long)N + q) * 3 + 0) * H + hh) * HD;
@@ -310,7 +331,7 @@ __global__ __launch_bounds__(256) void k_bwd_q(const T* __restrict__ qkv, const 
 // ---- backward, pass 2: a wave owns a 32-KEY tile; S is computed un-transposed (lane = key column, registers = 16 query rows):
 //   S[q, key] = (scale Q)[q, :] . K[key, :]   (A = scaled Q rows from LDS, B = the lane's K row in registers)
 //   dP[q, key] = dO[q, :] . V[key, :]         (A = dO rows from LDS, B = the lane's V row)
-//   dv^T[d, key] = sum_q dO^T[d, q] P[q, key],   dk^T[d, key] = sum_q (scale Q)^T[d, q] dS[q, key]   (A from transposed LDS tiles in sigma order)
+//   dv^T[d, key] = sum_q dO^T[d, q] P[q, key],   dk^T[d, key] = sum_q (scale Q)^T[d, q] dS[q, key]   (A: the same LDS tiles, read transposed)
 template <typename T>
 __global__ __launch_bounds__(256) void k_bwd_kv(const T* __restrict__ qkv, const float* __restrict__ bias, const int* __restrict__ region,
                                                 float scale, int NW, int N, int Np, int H, const T* __restrict__ dout,
@@ -320,9 +341,7 @@ __global__ __launch_bounds__(256) void k_bwd_kv(const T* __restrict__ qkv, const
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   E* Qs = reinterpret_cast<E*>(smem);                       // [Np][KROW] scaled q
   E* Gs = Qs + (size_t)Np * KROW;                           // [Np][KROW] dO
-  E* Qt = Gs + (size_t)Np * KROW;                           // [32][Np + 8]
-  E* Gt = Qt + (size_t)HD * (Np + 8);                       // [32][Np + 8]
-  float* Ls = reinterpret_cast<float*>(Gt + (size_t)HD * (Np + 8));   // [Np] lse (+inf on padding rows: P = 0)
+  float* Ls = reinterpret_cast<float*>(Gs + (size_t)Np * KROW);       // [Np] lse * log2(e) (+inf on padding rows: P = 0)
   float* Ds = Ls + Np;
   int* reg_s = reinterpret_cast<int*>(Ds + Np);
   const int bw = blockIdx.x / H, hh = blockIdx.x % H;
@@ -330,18 +349,13 @@ __global__ __launch_bounds__(256) void k_bwd_kv(const T* __restrict__ qkv, const
   const T* gbase = dout + (long long)bw * N * H * HD;
   stage_rows<T, E>(Qs, base, N, Np, H, hh, 0, scale);
   stage_out_rows<T, E>(Gs, gbase, N, Np, H, hh);
-  stage_transposed<T, E>(Qt, base, N, Np, H, hh, 0, scale);
-  stage_transposed<T, E>(Gt, gbase, N, Np, H, hh, -1, 1.f);
-  const int* reg_w = region ? region + (long long)(bw % NW) * N : nullptr;
   for (int j = threadIdx.x; j < Np; j += blockDim.x) {
-    Ls[j] = j < N ? lse[((long long)bw * H + hh) * N + j] : INFINITY;
+    Ls[j] = j < N ? lse[((long long)bw * H + hh) * N + j] * kLog2e : INFINITY;
     Ds[j] = j < N ? Dbuf[((long long)bw * H + hh) * N + j] : 0.f;
-    reg_s[j] = (reg_w && j < N) ? reg_w[j] : 0;
   }
-  __syncthreads();
+  const bool shifted = stage_regions(reg_s, region ? region + (long long)(bw % NW) * N : nullptr, N, Np);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const float* b = bias + (long long)hh * N * N;
-  const int ldt = Np + 8;
   for (int kt = wave; kt < Np / 32; kt += 4) {
     const int key = kt * 32 + r;
     const bool kok = key < N;
@@ -375,20 +389,24 @@ __global__ __launch_bounds__(256) void k_bwd_kv(const T* __restrict__ qkv, const
         sa = M::mfma(*reinterpret_cast<const typename M::v8*>(Qs + (qt + r) * KROW + 16 * s + 8 * h), kf[s], sa);
         dp = M::mfma(*reinterpret_cast<const typename M::v8*>(Gs + (qt + r) * KROW + 16 * s + 8 * h), vf[s], dp);
       }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sa[i] += bc[i];
+      if (shifted) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sa[i] += (reg_s[qt + key_of(i, h)] != rk) ? -100.f : 0.f;
+      }
       typename M::v8 pf[2], df[2];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int q = qt + key_of(i, h);                 // the same register <-> row map, rows are queries here
-        float v = sa[i] + bc[i];
-        v += (reg_s[q] != rk) ? -100.f : 0.f;
-        const float p = __expf(v - Ls[q]);               // padding rows: exp(-inf) = 0
+        const float p = exp_sub(sa[i], Ls[q]);           // padding rows: exp2(-inf) = 0
         pf[i >> 3][i & 7] = M::bits(p);
         df[i >> 3][i & 7] = M::bits(p * (dp[i] - Ds[q]));
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        dv = M::mfma(sigma_frag<T, E>(Gt, ldt, r, qt, s, h), pf[s], dv);
-        dk = M::mfma(sigma_frag<T, E>(Qt, ldt, r, qt, s, h), df[s], dk);
+        dv = M::mfma(tr_frag<T, E>(Gs, qt, s, lane), pf[s], dv);
+        dk = M::mfma(tr_frag<T, E>(Qs, qt, s, lane), df[s], dk);
       }
     }
     if (kok) {
@@ -411,7 +429,7 @@ inline int status() {
   return e == hipSuccess ? 0 : -(int)e;
 }
 
-inline size_t fwd_lds(int Np, size_t esz) { return (size_t)Np * KROW * esz + (size_t)HD * (Np + 8) * esz + (size_t)Np * sizeof(int); }
+inline size_t fwd_lds(int Np, size_t esz) { return (size_t)2 * Np * KROW * esz + (size_t)Np * sizeof(int); }
 
 template <typename T>
 int fwd_t(const void* qkv, const float* biasT, const int* region, float scale, int BW, int NW, int N, int H, void* out, float* lse,
@@ -426,10 +444,8 @@ int fwd_t(const void* qkv, const float* biasT, const int* region, float scale, i
   return status();
 }
 
-inline size_t bwd_q_lds(int Np, size_t esz) { return (size_t)2 * Np * KROW * esz + (size_t)HD * (Np + 8) * esz + (size_t)Np * sizeof(int); }
-inline size_t bwd_kv_lds(int Np, size_t esz) {
-  return (size_t)2 * Np * KROW * esz + (size_t)2 * HD * (Np + 8) * esz + (size_t)Np * (2 * sizeof(float) + sizeof(int));
-}
+inline size_t bwd_q_lds(int Np, size_t esz) { return (size_t)2 * Np * KROW * esz + (size_t)Np * sizeof(int); }
+inline size_t bwd_kv_lds(int Np, size_t esz) { return (size_t)2 * Np * KROW * esz + (size_t)Np * (2 * sizeof(float) + sizeof(int)); }
 
 template <typename T>
 int bwd_t(const void* qkv, const float* bias, const float* biasT, const int* region, float scale, int BW, int NW, int N, int H, const void* out,

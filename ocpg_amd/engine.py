@@ -84,7 +84,16 @@ def train_step(model, criterion, samples, captions, targets, optimizer, max_norm
         raise FloatingPointError("Loss is {}, stopping training: {}".format(loss_value, {k: float(v.detach()) for k, v in loss_dict.items()}))
     optimizer.zero_grad()
     params = [p for p in model.parameters() if p.requires_grad]
-    if grad_scaler is not None:
+    fused = hasattr(optimizer, "step_clip")        # optim.ClipAdamW: (unscale +) norm + clip + AdamW in three launches, no host sync
+    if fused and grad_scaler is not None:
+        grad_scaler.scale(losses).backward()
+        grad_scaler.step(optimizer, max_norm=max_norm)
+        grad_scaler.update()
+        norm = optimizer.grad_norm
+    elif fused:
+        losses.backward()
+        norm = optimizer.step_clip(max_norm)
+    elif grad_scaler is not None:
         grad_scaler.scale(losses).backward()
         if max_norm > 0:
             grad_scaler.unscale_(optimizer)

@@ -13,10 +13,17 @@ _CHUNK = 2048
 
 
 class ClipAdamW(torch.optim.AdamW):
+    # torch.amp.GradScaler.step(): "this optimizer handles grad_scale / found_inf itself" -- the scaler then hands both over as device
+    # tensors (optimizer.grad_scale / optimizer.found_inf) and does NOT read found_inf back to the host (torch/amp/grad_scaler.py
+    # _maybe_opt_step is the .item() this avoids).
+    _step_supports_amp_scaling = True
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, foreach=False, fused=False)
         self._tables = None
         self._steps = 0             # steps taken through step_clip since the state was created / loaded (mirrors state[p]["step"])
+        self.grad_norm = None       # pre-clip total norm of the last step's (unscaled) gradients, device scalar
+        self._amp = None            # fp32[6] on the device once a step ran under a GradScaler: [3] is then THE step count (skipped steps excluded)
 
     # ---- tables -----------------------------------------------------------------------------------------------------------------
     def _entries(self):
@@ -75,9 +82,15 @@ class ClipAdamW(torch.optim.AdamW):
 
     # ---- the step ---------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def step_clip(self, max_norm=0.0):
+    def step_clip(self, max_norm=0.0, grad_scale=None, found_inf=None, amp=False):
         """clip_grad_norm_(all parameters of the groups, max_norm) + step().  Returns the total gradient norm BEFORE clipping (device
-        scalar), or None when no parameter has a gradient."""
+        scalar), or None when no parameter has a gradient.
+
+        amp (or a grad_scale / found_inf tensor): the torch.amp.GradScaler form of engine.py:98-106 -- the gradients still carry
+        `grad_scale` (device scalar, None = already unscaled); the norm is that of the unscaled gradients, the step is skipped ON THE
+        DEVICE when the norm is not finite or `found_inf` is set, and skipped steps do not count (include/ocpg_hip.h,
+        ocpg_grad_norm_clip_amp)."""
+        amp = amp or grad_scale is not None or found_inf is not None
         ent = self._entries()
         if not ent:
             return None
@@ -95,6 +108,25 @@ class ClipAdamW(torch.optim.AdamW):
                 raise RuntimeError("ClipAdamW: betas / eps must be the same in every group")
         st = torch.cuda.current_stream().cuda_stream
         m = t["meta"]
+        if amp:
+            if self._amp is None:
+                self._amp = torch.zeros(6, dtype=torch.float32, device=m.device)
+                self._amp[3] = float(self._steps or int(self.state[t["params"][0]]["step"]))
+            for x in (grad_scale, found_inf):
+                if x is not None and (x.dtype != torch.float32 or x.device != m.device or x.numel() != 1):
+                    raise RuntimeError("ClipAdamW: grad_scale / found_inf must be one-element fp32 tensors on the parameters' device")
+            with torch.cuda.device(m.device):
+                check(lib().ocpg_grad_norm_clip_amp(m[1].data_ptr(), m[4].data_ptr(), m[5].data_ptr(), t["n"], t["chunks"], float(max_norm),
+                                                    t["partials"].data_ptr(), grad_scale.data_ptr() if grad_scale is not None else None,
+                                                    found_inf.data_ptr() if found_inf is not None else None, float(b1), float(b2),
+                                                    self._amp.data_ptr(), st), "ocpg_grad_norm_clip_amp")
+                check(lib().ocpg_adamw_step_amp(m[0].data_ptr(), m[1].data_ptr(), m[2].data_ptr(), m[3].data_ptr(), m[4].data_ptr(), m[5].data_ptr(),
+                                                hyper[0].data_ptr(), hyper[1].data_ptr(), t["n"], t["chunks"], self._amp.data_ptr(),
+                                                float(b1), float(b2), float(g0["eps"]), st), "ocpg_adamw_step_amp")
+            self.grad_norm = self._amp[0]
+            return self.grad_norm
+        if self._amp is not None:                  # back from scaler-driven steps: the device holds the count
+            self._steps, self._amp = int(self._amp[3]), None
         with torch.cuda.device(m.device):
             check(lib().ocpg_grad_norm_clip(m[1].data_ptr(), m[4].data_ptr(), m[5].data_ptr(), t["n"], t["chunks"], float(max_norm),
                                             t["partials"].data_ptr(), t["norm"].data_ptr(), st), "ocpg_grad_norm_clip")
@@ -102,25 +134,33 @@ class ClipAdamW(torch.optim.AdamW):
             check(lib().ocpg_adamw_step(m[0].data_ptr(), m[1].data_ptr(), m[2].data_ptr(), m[3].data_ptr(), m[4].data_ptr(), m[5].data_ptr(),
                                         hyper[0].data_ptr(), hyper[1].data_ptr(), t["n"], t["chunks"], t["norm"].data_ptr(),
                                         float(b1), float(b2), float(g0["eps"]), self._steps, st), "ocpg_adamw_step")
-        return t["norm"][0]
+        self.grad_norm = t["norm"][0]
+        return self.grad_norm
 
-    def step(self, closure=None):
-        """torch.optim.AdamW.step semantics (no clipping) through the same kernels."""
+    def step(self, closure=None, max_norm=0.0):
+        """torch.optim.AdamW.step semantics through the same kernels.  Under `scaler.step(optimizer, max_norm=...)` the scaler has set
+        .grad_scale / .found_inf (see _step_supports_amp_scaling): unscale + clip + step in the three launches, no host sync."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        self.step_clip(0.0)
+        gs, fi = getattr(self, "grad_scale", None), getattr(self, "found_inf", None)
+        self.step_clip(max_norm, grad_scale=gs, found_inf=fi)
         return loss
+
+    def steps_taken(self):
+        """Optimizer steps actually applied (steps a GradScaler skipped do not count).  Reads the device counter: a host sync."""
+        return int(self._amp[3]) if self._amp is not None else self._steps
 
     def _sync_steps(self):
         """state[p]["step"] of the parameters the kernels step (the tables' members) = the count the kernels were given; parameters
         that never received a gradient keep their own (torch.optim.AdamW does not step them either)."""
-        if self._steps and self._tables is not None:
+        steps = self.steps_taken()
+        if steps and self._tables is not None:
             for p in self._tables["params"]:
                 st = self.state.get(p)
                 if st is not None and "step" in st:
-                    st["step"] = torch.tensor(float(self._steps))
+                    st["step"] = torch.tensor(float(steps))
 
     def state_dict(self):
         self._sync_steps()
@@ -128,4 +168,4 @@ class ClipAdamW(torch.optim.AdamW):
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
-        self._tables, self._steps = None, 0
+        self._tables, self._steps, self._amp = None, 0, None

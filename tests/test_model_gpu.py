@@ -798,6 +798,9 @@ def test_fused_autocast_param_cast_equals_per_op_casts(golden, dev):
 
     def run(enabled):
         amp_cache.ENABLED = enabled
+        # this test isolates the CAST: kernels that only exist on the cached-copy side (the split-K neck convolution, round 4) would add their
+        # own summation-order differences to the on-vs-off comparison; they have their own tests (test_conv3x3_splitk_kernel)
+        splitk, amp_cache.SPLITK_3X3 = amp_cache.SPLITK_3X3, False
         try:
             torch.manual_seed(0)
             args, model, crit = model_checks.build_product(meta, dev)
@@ -819,6 +822,7 @@ def test_fused_autocast_param_cast_equals_per_op_casts(golden, dev):
             return out["pred_masks"].detach().float().cpu(), total.item(), gn
         finally:
             amp_cache.ENABLED = True
+            amp_cache.SPLITK_3X3 = splitk
 
     (m0, t0, g0), (m0b, t0b, g0b), (m1, t1, g1) = run(False), run(False), run(True)
     rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-20))
@@ -1364,6 +1368,58 @@ def test_clip_adamw_kernels_equal_torch(dev):
     assert all(float(v["step"]) == 4.0 for v in sd["state"].values())
     plain = torch.optim.AdamW(groups([torch.nn.Parameter(p.detach().clone(memory_format=torch.preserve_format)) for p in a]), lr=1e-2, weight_decay=5e-4)
     plain.load_state_dict(sd)                 # interchangeable with torch's optimizer (checkpoint wire format, row f2)
+
+
+def test_clip_adamw_under_grad_scaler_equals_torch(dev):
+    """`scaler.step(ClipAdamW, max_norm=...)` (unscale, norm, clip, skip-on-overflow and AdamW on the device, no found_inf.item()) against
+    the reference's sequence scaler.unscale_ + clip_grad_norm_ + scaler.step(torch.optim.AdamW) + scaler.update() (engine.py:98-106):
+    five steps of which the third carries an inf gradient -- both skip it, both halve the scale, and the bias corrections of the later
+    steps count FOUR steps, not five."""
+    from ocpg_amd.optim import ClipAdamW
+    torch.manual_seed(6)
+    shapes = [(257, 33), (64, 32, 3, 3), (5,), (1000, 130), (2049,)]
+    a = [torch.nn.Parameter(torch.randn(s, device=dev)) for s in shapes]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    groups = lambda ps: [{"params": ps[:2], "lr": 1e-2}, {"params": ps[2:], "lr": 1e-3}]   # noqa: E731
+    mine = ClipAdamW(groups(a), lr=1e-2, weight_decay=5e-4)
+    ref = torch.optim.AdamW(groups(b), lr=1e-2, weight_decay=5e-4, foreach=False, fused=False)
+    sa, sb = torch.amp.GradScaler("cuda", init_scale=1024.0, growth_interval=2), torch.amp.GradScaler("cuda", init_scale=1024.0, growth_interval=2)
+    scales = []
+    for it, (mag, max_norm) in enumerate(((1e-4, 0.1), (1.0, 0.1), (1.0, 0.1), (3.0, 0.1), (1.0, 0.0))):
+        gs = [torch.randn(s, device=dev) * mag for s in shapes]
+        if it == 2:
+            gs[3][17, 5] = float("inf")
+        for scaler, ps in ((sa, a), (sb, b)):
+            scaler.scale(torch.zeros((), device=dev))                    # (creates the scale tensor, as scaler.scale(loss) does)
+            for p, g in zip(ps, gs):
+                p.grad = g * scaler.get_scale()
+        before = [p.detach().clone() for p in a]
+        sa.step(mine, max_norm=max_norm)
+        sa.update()
+        sb.unscale_(ref)
+        want = torch.sqrt(sum(q.grad.double().square().sum() for q in b))
+        if max_norm > 0 and it != 2:
+            for q in b:
+                q.grad.mul_(min(1.0, max_norm / (float(want) + 1e-6)))
+        sb.step(ref)
+        sb.update()
+        scales.append((sa.get_scale(), sb.get_scale()))
+        if it == 2:
+            assert all(torch.equal(p, q) for p, q in zip(a, before)), "an overflowed step must leave the parameters alone"
+        else:
+            assert abs(float(mine.grad_norm) - float(want)) <= 4e-6 * float(want), (it, float(mine.grad_norm), float(want))
+        for i, (p, q) in enumerate(zip(a, b)):
+            assert torch.allclose(p, q, rtol=4e-6, atol=4e-7), (it, i, (p - q).abs().max().item())
+            for k in ("exp_avg", "exp_avg_sq"):
+                assert torch.allclose(mine.state[p][k], ref.state[q][k], rtol=4e-6, atol=1e-9), (it, i, k)
+    assert all(x == y for x, y in scales) and scales[2][0] < scales[1][0], scales
+    assert mine.steps_taken() == 4
+    assert all(float(v["step"]) == 4.0 for v in mine.state_dict()["state"].values())
+    # and back to un-scaled stepping: the count carries over
+    for p in a:
+        p.grad = torch.randn_like(p)
+    mine.step_clip(0.1)
+    assert mine.steps_taken() == 5
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
