@@ -408,6 +408,20 @@ int ocpg_attn_smallk_bwd(const void* q, long long ldq, const void* k, long long 
  * of x[ci] over the (h-2)x(w-2) window at offset (ky,kx).  x [planes, h, w] fp32 contiguous -> out [planes, 9] window means
  * (as_bf16 != 0: every element is rounded to bf16 first, as the autocast convolution would see it); bwd: gm [planes, 9] ->
  * dx [planes, h, w] fully written. */
+/* The LFM block's 2-D Fourier transforms on channels-last maps (csrc/lfm_dft.hip) -- replaces torch.fft.fft2 / ifft2 + the gate / cat /
+ * complex / .real / residual chain of LFMResizeAdaptive.forward (models/modules.py:44-56) and their backward:
+ *   ocpg_lfm_spectrum_fwd: x real fp32 [N,H,W,C] -> pair [N,H,W,2C] (dtype code pair_dt; channels [0,C) = Re, [C,2C) = Im) =
+ *       norm * fft2(x)[n,c,u,v] * (1 - coef[n] * high[u*W+v])   (coef / high NULL: no gate);
+ *   ocpg_lfm_spectrum_inv: pair -> out real fp32 [N,H,W,C] = norm * Re(sum_{u,v} pair_c[u,v] * gate * exp(+2 pi i (uy/H + vx/W)))
+ *       (+ residual, same layout as out, or NULL); coef_part (or NULL): [N, (W/2+1) * ceil(C/64)] partial sums of
+ *       d/dcoef = -sum high * (pair_re * S_re + pair_im * S_im), S = z_saved / gate (z_saved = the forward's gated pair, pair_dt).
+ * tw_h / tw_w: float2 [H] / [W] tables exp(-2 pi i k / L); tmp: scratch of N*H*(W/2+1)*C float2.  Lengths must factor as L1 * L2 with
+ * both <= 16 and be <= 128 (ocpg_lfm_dft_supported; -2000 otherwise: the caller keeps the library FFT). */
+int ocpg_lfm_dft_supported(int H, int W);
+int ocpg_lfm_spectrum_fwd(const float* x, const float* coef, const float* high, int N, int H, int W, int C, const void* tw_h, const void* tw_w,
+                          float norm, void* tmp, void* pair, int pair_dt, void* stream);
+int ocpg_lfm_spectrum_inv(const void* pair, int pair_dt, const float* coef, const float* high, const void* z_saved, float* coef_part, int N, int H,
+                          int W, int C, const void* tw_h, const void* tw_w, float norm, void* tmp, const float* residual, float* out, void* stream);
 int ocpg_window_means3x3_fwd(const float* x, long long planes, int h, int w, int as_bf16, float* out, void* stream);
 int ocpg_window_means3x3_bwd(const float* gm, long long planes, int h, int w, float* dx, void* stream);
 

@@ -85,6 +85,9 @@ SIGNATURES = {
     "ocpg_adamw_step": [_vp] * 8 + [_int, ctypes.c_longlong, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_longlong, _vp],
     "ocpg_grad_norm_clip_amp": [_vp] * 3 + [_int, ctypes.c_longlong, ctypes.c_float, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, _vp, _vp],
     "ocpg_adamw_step_amp": [_vp] * 8 + [_int, ctypes.c_longlong, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp],
+    "ocpg_lfm_dft_supported": [_int, _int],
+    "ocpg_lfm_spectrum_fwd": [_vp, _vp, _vp] + [_int] * 4 + [_vp, _vp, ctypes.c_float, _vp, _vp, _int, _vp],
+    "ocpg_lfm_spectrum_inv": [_vp, _int, _vp, _vp, _vp, _vp] + [_int] * 4 + [_vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp],
     "ocpg_colsum_partials": [_vp, ctypes.c_longlong, _int, _int, _vp, _vp],
     "ocpg_det_loss_fwd_f32": [_vp] * 7 + [ctypes.c_float] + [_int] * 5 + [_vp] * 3,
     "ocpg_det_loss_bwd_f32": [_vp] * 8 + [ctypes.c_float] + [_int] * 5 + [_vp] * 3,

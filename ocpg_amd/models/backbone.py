@@ -66,6 +66,7 @@ class FrozenBatchNorm2d(nn.Module):
 
 FUSED_CONV_BN = os.environ.get("OCPG_FUSED_CONV_BN", "1") != "0"     # A/B switch
 MFMA_CONV3X3 = os.environ.get("OCPG_MFMA_CONV3X3", "1") != "0"     # A/B switch: 3x3 conv + BN + ReLU by csrc/conv3x3_mfma.hip (bf16, >= 128 channels)
+STRIDED_1X1 = os.environ.get("OCPG_STRIDED_1X1", "1") != "0"     # A/B switch: the stride-2 projection shortcuts as subsample + GEMM (else MIOpen)
 FUSED_CONV3X3_BN = os.environ.get("OCPG_FUSED_CONV3X3_BN", "0") != "0"     # opt-in: 3x3 conv + BN + ReLU as im2col + epilogue GEMM (small maps); measured neutral in the step
 
 
@@ -73,6 +74,13 @@ def conv_bn_act(conv, bn, x, skip, relu):
     """act(bn(conv(x)) (+ skip)).  1x1/stride-1 convs of channels-last GPU maps: one fused autograd node (hipBLASLt GEMM
     through the plan cache + the frozen-BN HIP kernel in place, ops/functions/conv_bn_func.py); anything else: the two
     modules in sequence."""
+    if STRIDED_1X1 and FUSED_CONV_BN and amp_cache.GEMM_1X1 and conv_bn_func.eligible_s2(x, conv):
+        w = amp_cache.lookup(conv.weight)
+        if w.dtype == x.dtype:
+            scale, shift = bn.scale_shift()
+            xs = conv_bn_func.subsample2(x)
+            n, _, h, wd = xs.shape
+            return conv_bn_func.conv1x1_bn_act(xs, w, scale, shift, skip, relu, amp_cache._split_rows(n * h * wd) if amp_cache.SPLIT_K else 1)
     if FUSED_CONV_BN and amp_cache.GEMM_1X1 and conv_bn_func.eligible(x, conv):
         w = amp_cache.lookup(conv.weight)
         if w.dtype == x.dtype:

@@ -11,10 +11,14 @@ from torch import nn
 
 from ..util.misc import memo
 from . import amp_cache
-from .ops.functions.spectral_func import conv3x3_valid_spatial_mean, ifft2_real, pair_to_complex, spectral_gate, spectral_gate_cl
+import os
+
+from .ops.functions.spectral_func import (conv3x3_valid_spatial_mean, dft_supported, ifft2_real, lfm_inverse, lfm_spectrum, pair_to_complex,
+                                          spectral_gate, spectral_gate_cl)
 
 FUSED_GATE = True       # A/B switch: fused spectral gate kernel
 GATE_NHWC = True        # A/B switch: gate output / inverse-FFT input in channels-last memory (1x1 convs as GEMMs, no casts / layout copies)
+DFT_CL = os.environ.get("OCPG_LFM_DFT", "1") != "0"       # A/B switch: both transforms by csrc/lfm_dft.hip on the channels-last map (else rocFFT between transposes)
 LAPLACE_MEAN = True     # A/B switch: mean(laplace(x)) as nine window means + one small matrix product (no convolution)
 
 
@@ -67,6 +71,10 @@ class LFMResizeAdaptive(nn.Module):
             high._ocpg_key = key
         if x.is_cuda and FUSED_GATE and GATE_NHWC and c % 4 == 0:
             dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
+            if DFT_CL and dft_supported(h, w):
+                z = lfm_spectrum(x, coef.float().reshape(b), high.reshape(h, w), dt)      # fft2 + gate + [Re || Im], channels-last
+                y = self.conv2(F.relu(self.conv1(z)))
+                return lfm_inverse(y, x), high                                          # x + ifft2(.).real
             z = spectral_gate_cl(torch.fft.fft2(x), coef.float().reshape(b), high.reshape(h, w), dt)
             y = self.conv2(F.relu(self.conv1(z)))                   # channels-last in, channels-last out: two GEMMs
             y = ifft2_real(pair_to_complex(y), h, w)              # = torch.fft.ifft2(..., s=(h, w)).real, real-to-complex backward

@@ -16,6 +16,7 @@ MI355X-first differences in HOW (results agree to fp32 rounding):
 """
 import copy
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -36,6 +37,7 @@ from .postprocessors import build_postprocessors
 from .resample import bicubic_resize, bilinear_resize, nearest_upsample
 
 MATMUL_BILINEAR = True       # A/B switch: bilinear resampling as two matrix products (no atomics backward)
+LS_FEAT_N16 = os.environ.get("OCPG_LS_FEAT_N16", "1") != "0"     # A/B switch: ls_feat_viz (3x3, 256 -> 8) by csrc/mso.hip's <= 16-output kernels
 from .segmentation import VisionLanguageFusionModule
 from .text_encoder.text_encoder import FeatureResizer, PrecomputedText, TextEncoder
 
@@ -300,7 +302,7 @@ class OCPG(nn.Module):
                     out["aux_outputs"] = self._set_aux_loss(outputs_class, outputs_coord, seg_masks_shuffled)
                     out["aux_matcher_index"] = [self.matcher.as_indices(src_all[i]) for i in range(nl - 1)]
             if self.aux_loss:
-                lsf = self.ls_feat_viz(memory_fusion)
+                lsf = self._ls_feat(memory_fusion)
                 ls_feat = (bilinear_resize(lsf, (4 * lsf.shape[-2], 4 * lsf.shape[-1]), True) if lsf.is_cuda and MATMUL_BILINEAR
                            else F.interpolate(lsf, scale_factor=4, mode="bilinear", align_corners=True))
                 ls_feat = ls_feat.unflatten(0, (b, t))                              # [b, t, 8, 4h, 4w]
@@ -351,6 +353,20 @@ class OCPG(nn.Module):
         return out
 
     @torch.jit.unused
+    def _ls_feat(self, x):
+        """ls_feat_viz (ocpg.py:71 of the reference: Conv2d(hidden, 8, 3, 1, 1)) on the GPU: the <= 16-output-channel MFMA kernels of
+        csrc/mso.hip (forward, input gradient, weight + bias gradient) on the channels-last map, operands in the autocast dtype with fp32
+        accumulation as an autocast convolution has; the library convolution otherwise."""
+        conv = self.ls_feat_viz
+        if not (LS_FEAT_N16 and x.is_cuda and x.shape[0] <= 65535 and x.dtype in (torch.float32, torch.bfloat16, torch.float16)):
+            return conv(x)
+        from .decoder import _bias32, _nhwc, _tap_major
+        from .ops.functions.mso_func import compute_code, conv3x3_n16
+        cdt = compute_code(x.device.type)
+        y = conv3x3_n16(_nhwc(x), _tap_major(amp_cache.lookup(conv.weight), cdt), _bias32(conv.bias), cdt=cdt)       # [N, h, w, 8] fp32
+        y = y.permute(0, 3, 1, 2)
+        return y if cdt == 0 else y.to(torch.get_autocast_dtype(x.device.type))          # an autocast convolution returns the autocast dtype
+
     def _set_aux_loss(self, outputs_class, outputs_coord, outputs_seg_masks):
         return [{"pred_logits": a, "pred_boxes": b_, "pred_masks": c}
                 for a, b_, c in zip(outputs_class[:-1], outputs_coord[:-1], outputs_seg_masks[:-1])]

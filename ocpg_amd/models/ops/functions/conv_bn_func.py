@@ -64,6 +64,34 @@ def eligible(x, conv):
             and conv.groups == 1 and conv.bias is None and x.is_contiguous(memory_format=_CL))
 
 
+def eligible_s2(x, conv):
+    """A 1x1 / stride-2 convolution (the projection shortcut of layer2-4's first block, torchvision resnet.py `downsample`) = the
+    stride-1 GEMM on every other pixel of every other row."""
+    return (x.is_cuda and x.dim() == 4 and x.dtype in _DT and conv.kernel_size == (1, 1) and conv.stride == (2, 2) and conv.padding == (0, 0)
+            and conv.groups == 1 and conv.bias is None and x.is_contiguous(memory_format=_CL))
+
+
+class Subsample2(Function):
+    """x[:, :, ::2, ::2] as a channels-last map; backward: the gradient written into the even pixels of a zeroed map (two launches;
+    autograd's own slice backward is two zero-fills + two strided copies)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = x.shape
+        return x[:, :, ::2, ::2].contiguous(memory_format=_CL)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        gx = torch.empty(ctx.shape, dtype=g.dtype, device=g.device, memory_format=_CL).zero_()
+        gx[:, :, ::2, ::2] = g
+        return gx
+
+
+def subsample2(x):
+    return Subsample2.apply(x)
+
+
 class Conv1x1BNAct(Function):
     @staticmethod
     def forward(ctx, x, w, scale, shift, skip, relu, splits):
@@ -265,11 +293,14 @@ def conv3x3_bn_act(x, w, scale, shift, relu, stride, dil, splits):
 # ---- 3x3 conv (padding 1, stride 1|2) + frozen BN + ReLU on the matrix cores: csrc/conv3x3_mfma.hip ------------------------
 def eligible3x3_mfma(x, conv):
     """bf16 channels-last map, 3x3 / padding 1 / dilation 1 / stride 1|2 / no bias, channel counts the kernel's K step and its
-    128-wide output tile serve well (>= 128: ResNet layers 2-4; the 64-channel layer1 keeps MIOpen)."""
+    output tile serve (multiples of 64, >= _MFMA_MIN_C: ResNet layers 2-4; the 64-channel layer1 keeps MIOpen, which is faster there)."""
     return (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and conv.kernel_size == (3, 3) and conv.groups == 1
             and conv.bias is None and conv.stride[0] == conv.stride[1] and conv.stride[0] in (1, 2) and conv.dilation == (1, 1)
             and conv.padding == (1, 1) and conv.padding_mode == "zeros" and x.is_contiguous(memory_format=_CL)
-            and x.shape[1] % 64 == 0 and conv.out_channels % 64 == 0 and x.shape[1] >= 128 and conv.out_channels >= 128)
+            and x.shape[1] % 64 == 0 and conv.out_channels % 64 == 0 and x.shape[1] >= _MFMA_MIN_C and conv.out_channels >= _MFMA_MIN_C)
+
+
+_MFMA_MIN_C = int(os.environ.get("OCPG_MFMA_CONV3X3_MIN_C", "128"))     # 64 also serves layer1 (frozen: forward only), measured 0.08 ms/step SLOWER than MIOpen there (r4)
 
 
 class Conv3x3MfmaBNAct(Function):

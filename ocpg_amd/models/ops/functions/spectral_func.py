@@ -161,3 +161,119 @@ class IFFT2Real(Function):
 
 def ifft2_real(z, h, w):
     return IFFT2Real.apply(z, int(h), int(w))
+
+
+# ---- the transforms themselves on channels-last maps (csrc/lfm_dft.hip) ---------------------------------------------------------
+def dft_supported(h, w):
+    return bool(lib().ocpg_lfm_dft_supported(int(h), int(w)))
+
+
+def _twiddles(n, device):
+    """exp(-2 pi i k / n), k < n, formed in fp64: float2 [n]"""
+    from ....util.misc import memo
+
+    def make():
+        a = torch.arange(n, dtype=torch.float64) * (-2.0 * torch.pi / n)
+        return torch.stack([a.cos(), a.sin()], -1).float().to(device)
+    return memo("lfm_tw", n, device, make)
+
+
+def _nhwc32(x):
+    """[N, C, h, w] -> its channels-last memory as an fp32 [N, h, w, C] contiguous tensor (a view when it already is)."""
+    v = x.permute(0, 2, 3, 1)
+    if v.dtype != torch.float32:
+        v = v.float()
+    return v if v.is_contiguous() else v.contiguous()
+
+
+def _pair_cl(y):
+    v = y.permute(0, 2, 3, 1)
+    if v.dtype not in _DT:
+        v = v.float()
+    return v if v.is_contiguous() else v.contiguous()
+
+
+def _spectrum(x_nhwc, coef, high, norm, dtype):
+    n, h, w, c = x_nhwc.shape
+    dev = x_nhwc.device
+    tmp = torch.empty((n, h, w // 2 + 1, c, 2), dtype=torch.float32, device=dev)
+    pair = torch.empty((n, h, w, 2 * c), dtype=dtype, device=dev)
+    check(lib().ocpg_lfm_spectrum_fwd(x_nhwc.data_ptr(), coef.data_ptr() if coef is not None else None,
+                                      high.data_ptr() if high is not None else None, n, h, w, c, _twiddles(h, dev).data_ptr(),
+                                      _twiddles(w, dev).data_ptr(), float(norm), tmp.data_ptr(), pair.data_ptr(), _DT[dtype],
+                                      torch.cuda.current_stream().cuda_stream), "ocpg_lfm_spectrum_fwd")
+    return pair
+
+
+def _inverse(pair, coef, high, z_saved, want_coef, norm, residual):
+    n, h, w, c2 = pair.shape
+    c = c2 // 2
+    dev = pair.device
+    tmp = torch.empty((n, h, w // 2 + 1, c, 2), dtype=torch.float32, device=dev)
+    out = torch.empty((n, h, w, c), dtype=torch.float32, device=dev)
+    part = torch.empty((n, (w // 2 + 1) * ((c + 63) // 64)), dtype=torch.float32, device=dev) if want_coef else None
+    check(lib().ocpg_lfm_spectrum_inv(pair.data_ptr(), _DT[pair.dtype], coef.data_ptr() if coef is not None else None,
+                                      high.data_ptr() if high is not None else None, z_saved.data_ptr() if want_coef else None,
+                                      part.data_ptr() if want_coef else None, n, h, w, c, _twiddles(h, dev).data_ptr(), _twiddles(w, dev).data_ptr(),
+                                      float(norm), tmp.data_ptr(), residual.data_ptr() if residual is not None else None, out.data_ptr(),
+                                      torch.cuda.current_stream().cuda_stream), "ocpg_lfm_spectrum_inv")
+    return out, part
+
+
+class LFMSpectrum(Function):
+    """z = cat([Re, Im], 1)(fft2(x) * (1 - coef * high)) of a real map (models/modules.py:44-50) as a [N, 2C, h, w] tensor in
+    channels-last memory and the 1x1 convs' compute dtype: two passes of csrc/lfm_dft.hip.  Backward: the real part of the unnormalised
+    inverse transform of gate * gz, and the gate coefficient's gradient from the saved z."""
+
+    @staticmethod
+    def forward(ctx, x, coef, high, dtype):
+        xs = _nhwc32(x)
+        coef, high = coef.float().contiguous(), high.float().contiguous()
+        pair = _spectrum(xs, coef, high, 1.0, dtype)
+        ctx.save_for_backward(pair, coef, high)
+        return pair.permute(0, 3, 1, 2)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gz):
+        pair, coef, high = ctx.saved_tensors
+        g = _pair_cl(gz)
+        if g.dtype != pair.dtype:
+            g = g.to(pair.dtype)
+        want_coef = ctx.needs_input_grad[1]
+        gx, part = _inverse(g, coef, high, pair, want_coef, 1.0, None)
+        return gx.permute(0, 3, 1, 2), (part.sum(1) if want_coef else None), None, None
+
+
+class LFMInverse(Function):
+    """x + ifft2(complex(y[:, :C], y[:, C:]), s=(h, w)).real (models/modules.py:52-56) for y in channels-last memory, as two passes of
+    csrc/lfm_dft.hip; fp32 result in channels-last memory.  Backward: fft2(g) / (h w) as a [Re || Im] pair in y's dtype; g for x."""
+
+    @staticmethod
+    def forward(ctx, y, x):
+        ys, xs = _pair_cl(y), _nhwc32(x)
+        n, h, w, _ = ys.shape
+        out, _ = _inverse(ys, None, None, None, False, 1.0 / (h * w), xs)
+        ctx.dtype = (y.dtype, ys.dtype)
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        ydt, sdt = ctx.dtype
+        gy = None
+        if ctx.needs_input_grad[0]:
+            gs = _nhwc32(g)
+            n, h, w, _ = gs.shape
+            gy = _spectrum(gs, None, None, 1.0 / (h * w), sdt).permute(0, 3, 1, 2)
+            if gy.dtype != ydt:
+                gy = gy.to(ydt)
+        return gy, (g if ctx.needs_input_grad[1] else None)
+
+
+def lfm_spectrum(x, coef, high, dtype):
+    return LFMSpectrum.apply(x, coef, high, dtype)
+
+
+def lfm_inverse(y, x):
+    return LFMInverse.apply(y, x)

@@ -135,6 +135,39 @@ def check_e2e_swin(g, dev, rtol=5e-4, atol=5e-5):
     assert not bad, bad[:6]
 
 
+# norm-relative bounds of the 16-bit storage paths against the reference's fp32 vectors: (y, gx, parameter-gradient norms).  fp16 keeps 11
+# mantissa bits, bf16 8: the bf16 bounds are the fp16 ones x 8.  Measured on MI355X (r4): fp16 y 4e-4, gx 9e-4; bf16 y 3e-3, gx 7e-3.
+TOL16 = {torch.float16: (5e-3, 1e-2, 2e-2), torch.bfloat16: (2e-2, 4e-2, 6e-2)}
+
+
+def check_window_attention_16bit(g, dev, dtype):
+    """swin3d.npz's head_dim-32 case (clamped window (5,7,7) = 245 tokens, 3 heads, 8 windows of which 4 are shifted) through the
+    matrix-core kernels (csrc/win_attn_mfma.hip serves 16-bit storage only) under autocast, against the reference's fp32 vectors."""
+    import ocpg_amd.models.video_swin_transformer as vs
+    wc = vs.WindowAttention3D(96, (8, 7, 7), 3, qkv_bias=True)
+    _load(wc, g.meta["wc_shapes"], 11)
+    wc.to(dev)
+    blk = vs.SwinTransformerBlock3D(96, 3, window_size=(8, 7, 7), shift_size=(4, 3, 3))
+    regionc = blk._plan(5, 14, 14, dev)[3]
+    xw = synth.rand("wc_x", (8, 245, 96)).to(dev).requires_grad_(True)
+    ty, tg, tn = TOL16[dtype]
+    rel = lambda a, b: float((a.detach().float().cpu() - b).norm() / b.norm())    # noqa: E731
+    seen = {}
+    for tag, use_mask in (("nomask", False), ("mask", True)):
+        with torch.autocast(dev.type, dtype=dtype):
+            y = wc(xw, None, regionc if use_mask else None)
+        assert y.dtype == dtype
+        grads = torch.autograd.grad((y.float() * synth.rand("wc_go", y.shape).to(dev)).sum(), [xw] + list(wc.parameters()))
+        seen[tag] = (rel(y, g[f"wc_{tag}_y"]), rel(grads[0], g[f"wc_{tag}_gx"]))
+        assert seen[tag][0] <= ty and seen[tag][1] <= tg, (tag, seen)
+        for (k, _), gg in zip(wc.named_parameters(), grads[1:]):
+            ref = g.meta[f"wc_{tag}_grad_norms"][k]
+            assert abs(gg.float().norm().item() - ref) <= tn * abs(ref) + 1e-5, (tag, k, gg.norm().item(), ref)
+            if "bias_table" in k:
+                assert rel(gg, g[f"wc_{tag}_gtable"]) <= tg, (tag, rel(gg, g[f"wc_{tag}_gtable"]))
+    print("window attention %s vs fp32 vectors (rel y, rel gx): %s" % (dtype, seen))
+
+
 def check_window_attention_n392(g, dev, dtype=torch.float32, rtol=5e-4, atol=5e-5):
     """Config #5's window: the full (8,7,7) = 392 tokens, head_dim 32, 4 shifted windows; fp32, or fp16 storage (the
     reference's --amp) against the same fp32 vectors."""
@@ -156,9 +189,10 @@ def check_window_attention_n392(g, dev, dtype=torch.float32, rtol=5e-4, atol=5e-
             close(grads[0], g[f"{tag}_gx"], rtol * 10, atol * 10, f"n392 {tag} gx")
         else:       # 16-bit storage of q/k/v/out: norm-relative bounds
             rel = lambda a, b: float((a.detach().float().cpu() - b).norm() / b.norm())    # noqa: E731
-            assert rel(y, g[f"{tag}_y"]) <= 5e-3, rel(y, g[f"{tag}_y"])
-            assert rel(grads[0], g[f"{tag}_gx"]) <= 1e-2, rel(grads[0], g[f"{tag}_gx"])
-        tol = 2e-3 if dtype == torch.float32 else 2e-2
+            assert rel(y, g[f"{tag}_y"]) <= TOL16[dtype][0], rel(y, g[f"{tag}_y"])
+            assert rel(grads[0], g[f"{tag}_gx"]) <= TOL16[dtype][1], rel(grads[0], g[f"{tag}_gx"])
+            print("n392 %s %s (rel y, rel gx): %.2e %.2e" % (dtype, tag, rel(y, g[f"{tag}_y"]), rel(grads[0], g[f"{tag}_gx"])))
+        tol = 2e-3 if dtype == torch.float32 else TOL16[dtype][2]
         for (k, _), gg in zip(wa.named_parameters(), grads[1:]):
             ref = g.meta[f"{tag}_grad_norms"][k]
             assert abs(gg.float().norm().item() - ref) <= tol * abs(ref) + 1e-5, (tag, k, gg.norm().item(), ref)

@@ -438,6 +438,76 @@ def test_lfm_channels_last_gate(dev, amp):
                 ((b_ - r).abs().max().item(), (a - r).abs().max().item(), scale)
 
 
+@pytest.mark.parametrize("n,c,h,w", [(2, 36, 5, 13), (3, 70, 9, 14), (2, 64, 12, 20), (1, 130, 7, 16), (2, 256, 48, 80), (2, 8, 1, 6), (1, 5, 16, 1),
+                                     (1, 40, 128, 3), (2, 33, 6, 121)])
+def test_lfm_dft_kernels_equal_torch_fft(dev, n, c, h, w):
+    """csrc/lfm_dft.hip (both LFM transforms on the channels-last map, round 4) against torch.fft on the same tensors, forward and every
+    gradient: z = cat(Re, Im)(fft2(x) * (1 - coef * high)) and x + ifft2(complex(y[:, :C], y[:, C:])).real (models/modules.py:44-56).
+    Odd / prime / composite lengths (5 = 1 x 5, 13 = 1 x 13, 14 = 2 x 7, 80 = 8 x 10, 121 = 11 x 11, 128 = 8 x 16), lengths 1, channel
+    counts that are not multiples of the 64-channel slab."""
+    from ocpg_amd.models.ops.functions import spectral_func as sf
+    torch.manual_seed(h * 131 + w)
+    assert sf.dft_supported(h, w)
+    x = torch.randn(n, c, h, w, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    coef = torch.rand(n, device=dev).requires_grad_(True)
+    high = torch.rand(h, w, device=dev)
+    z = sf.lfm_spectrum(x, coef, high, torch.float32)
+    assert z.shape == (n, 2 * c, h, w) and z.permute(0, 2, 3, 1).is_contiguous()
+    spec = torch.fft.fft2(x) * (1 - coef.view(n, 1, 1, 1) * high)
+    want = torch.cat([spec.real, spec.imag], 1)
+    scale = want.abs().max().item()
+    assert (z - want).abs().max().item() <= 2e-6 * scale * max(1.0, (h * w) ** 0.5 / 8), ((z - want).abs().max().item(), scale)
+    go = torch.randn_like(want)
+    for name, a, b_ in zip(("gx", "gcoef"), torch.autograd.grad((z * go).sum(), (x, coef)), torch.autograd.grad((want * go).sum(), (x, coef))):
+        assert (a - b_).abs().max().item() <= 3e-5 * b_.abs().max().item() + 1e-6, (name, (a - b_).abs().max().item(), b_.abs().max().item())
+    y = torch.randn(n, 2 * c, h, w, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    r = sf.lfm_inverse(y, x)
+    want_r = x + torch.fft.ifft2(torch.complex(*torch.chunk(y, 2, dim=1)), s=(h, w)).real
+    assert r.shape == want_r.shape and (r - want_r).abs().max().item() <= 3e-6 * want_r.abs().max().item()
+    gr = torch.randn_like(want_r)
+    for name, a, b_ in zip(("gy", "gx"), torch.autograd.grad((r * gr).sum(), (y, x)), torch.autograd.grad((want_r * gr).sum(), (y, x))):
+        assert (a - b_).abs().max().item() <= 3e-5 * b_.abs().max().item() + 1e-7, (name, (a - b_).abs().max().item(), b_.abs().max().item())
+    assert not sf.dft_supported(23, 37) and not sf.dft_supported(8, 34) and not sf.dft_supported(130, 8)
+
+
+@pytest.mark.parametrize("amp", [None, torch.bfloat16])
+def test_lfm_block_own_transforms_equal_library_fft(dev, amp):
+    """The LFM block with csrc/lfm_dft.hip (default) == the same block on rocFFT between the transposing kernels (OCPG_LFM_DFT=0), two
+    chained levels (the second resizes the first's Gaussian), output / input gradients / every parameter gradient; under autocast both
+    are held against the fp32 run, the new path no further from it than the library path + the bf16 storage noise."""
+    from ocpg_amd import _lib
+    from ocpg_amd.models import modules
+    torch.manual_seed(1)
+    lfm = modules.LFMResizeAdaptive(72, 7).to(dev)
+    x1 = torch.randn(3, 72, 24, 40, device=dev).contiguous(memory_format=torch.channels_last)
+    x2 = torch.randn(3, 72, 12, 20, device=dev)
+
+    def run(on, dtype):
+        modules.DFT_CL = on
+        try:
+            a, b_ = x1.clone(memory_format=torch.preserve_format).requires_grad_(True), x2.clone().requires_grad_(True)
+            lfm.zero_grad()
+            calls = _lib.census(True)
+            with torch.autocast("cuda", dtype=dtype, enabled=dtype is not None):
+                y1, g = lfm(a)
+                y2, _ = lfm(b_, g)
+            (y1.float().square().mean() + y2.float().square().mean()).backward()
+            _lib.census(False)
+            assert (calls.get("ocpg_lfm_spectrum_fwd", 0), calls.get("ocpg_lfm_spectrum_inv", 0)) == ((4, 4) if on else (0, 0)), calls
+            return [y1.detach().float(), y2.detach().float(), a.grad, b_.grad] + [p.grad.clone() for p in lfm.parameters()]
+        finally:
+            modules.DFT_CL = True
+    if amp is None:
+        for u, v in zip(run(True, None), run(False, None)):
+            assert (u - v).abs().max().item() <= 3e-5 * v.abs().max().item() + 1e-7, ((u - v).abs().max().item(), v.abs().max().item())
+    else:
+        ref, lib_, own = run(False, None), run(False, amp), run(True, amp)
+        for r, a, b_ in zip(ref, lib_, own):
+            scale = r.abs().max().item()
+            assert (b_ - r).abs().max().item() <= 1.5 * (a - r).abs().max().item() + 1e-2 * scale + 1e-7, \
+                ((b_ - r).abs().max().item(), (a - r).abs().max().item(), scale)
+
+
 @pytest.mark.parametrize("amp", [None, torch.bfloat16])
 def test_lfm_laplace_mean_without_convolution(dev, amp):
     """LFM coefficient branch: nine window means + one small matrix product (csrc/lfm.hip) == conv3x3(valid) followed by the
@@ -767,11 +837,33 @@ def test_swin_window_attention_and_masks(golden, dev):
     sc.check_window_attention(golden("swin3d"), dev, rtol=5e-4, atol=5e-5)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
 def test_swin_window_attention_full_window_n392(golden, dev, dtype):
-    """BASELINE config #5's attention shape (N = 392) in fp32 and in fp16 storage (the reference's --amp), csrc/win_attn.hip."""
+    """BASELINE config #5's attention shape (N = 392) in fp32 (csrc/win_attn.hip), in fp16 storage (the reference's --amp) and in bf16
+    (config #4's dtype) -- the 16-bit ones through the matrix-core kernels (csrc/win_attn_mfma.hip), which the census checks."""
     import swin_checks as sc
-    sc.check_window_attention_n392(golden("swin_n392"), dev, dtype)
+    from ocpg_amd import _lib
+    c = _lib.census(True)
+    try:
+        sc.check_window_attention_n392(golden("swin_n392"), dev, dtype)
+    finally:
+        _lib.census(False)
+    assert c.get("ocpg_win_attn_fwd", 0) == 2, c
+    assert c.get("ocpg_win_attn_bwd_mfma" if dtype != torch.float32 else "ocpg_win_attn_bwd", 0) == 2 and \
+        (dtype == torch.float32 or "ocpg_win_attn_bwd" not in c), c
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_swin_window_attention_mfma_vs_reference_vectors(golden, dev, dtype):
+    """The matrix-core window attention on the reference's own swin3d.npz vectors (245-token clamped window, shifted-window regions)."""
+    import swin_checks as sc
+    from ocpg_amd import _lib
+    c = _lib.census(True)
+    try:
+        sc.check_window_attention_16bit(golden("swin3d"), dev, dtype)
+    finally:
+        _lib.census(False)
+    assert c.get("ocpg_win_attn_bwd_mfma", 0) == 2 and "ocpg_win_attn_bwd" not in c, c
 
 
 def test_swin_block_and_backbone(golden, dev):

@@ -87,3 +87,14 @@ for k, (t, n) in sorted(bymod.items(), key=lambda kv: -kv[1][0])[:60]:
 print("---- per (module, op), by launches")
 for (label, name), (t, n) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get("TOP", "150"))]:
     print("%8.1f us %5d  %-32s %s" % (t, n, name[:32], label[:110]))
+print("---- ATen ops only, by device time")
+aten = {k: v for k, v in agg.items() if k[1].startswith("aten::")}
+print("ATen total %.2f ms over %d ops" % (sum(v[0] for v in aten.values()) / 1e3, sum(v[1] for v in aten.values())))
+for (label, name), (t, n) in sorted(aten.items(), key=lambda kv: -kv[1][0])[:int(os.environ.get("TOP", "150"))]:
+    print("%8.1f us %5d  %-28s %s" % (t, n, name[:28], label[:120]))
+byop = collections.defaultdict(lambda: [0.0, 0])
+for (label, name), (t, n) in aten.items():
+    byop[name][0] += t; byop[name][1] += n
+print("---- ATen by op")
+for k, (t, n) in sorted(byop.items(), key=lambda kv: -kv[1][0])[:40]:
+    print("%8.1f us %5d  %s" % (t, n, k))
