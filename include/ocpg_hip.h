@@ -415,15 +415,23 @@ int ocpg_attn_smallk_bwd(const void* q, long long ldq, const void* k, long long 
  *   ocpg_lfm_spectrum_inv: pair -> out real fp32 [N,H,W,C] = norm * Re(sum_{u,v} pair_c[u,v] * gate * exp(+2 pi i (uy/H + vx/W)))
  *       (+ residual, same layout as out, or NULL); coef_part (or NULL): [N, (W/2+1) * ceil(C/64)] partial sums of
  *       d/dcoef = -sum high * (pair_re * S_re + pair_im * S_im), S = z_saved / gate (z_saved = the forward's gated pair, pair_dt).
- * tw_h / tw_w: float2 [H] / [W] tables exp(-2 pi i k / L); tmp: scratch of N*H*(W/2+1)*C float2.  Lengths must factor as L1 * L2 with
- * both <= 16 and be <= 128 (ocpg_lfm_dft_supported; -2000 otherwise: the caller keeps the library FFT). */
+ * tmp: scratch of N*H*(W/2+1)*C float2.  Lengths must factor as L1 * L2 with both <= 16 and be <= 128 (ocpg_lfm_dft_supported;
+ * ocpg_lfm_dft_split(L) = L1 * 256 + L2, 0 when not served; -2000 from the transforms: the caller keeps the library FFT).
+ * tw_h / tw_w: the float2 tables of the length: [0, L) exp(-2 pi i m / L); then the L1-point DFT matrix exp(-2 pi i j k / L1) at
+ * [k * L1 + j]; then the L2-point one -- L + L1^2 + L2^2 entries. */
 int ocpg_lfm_dft_supported(int H, int W);
+int ocpg_lfm_dft_split(int L);
 int ocpg_lfm_spectrum_fwd(const float* x, const float* coef, const float* high, int N, int H, int W, int C, const void* tw_h, const void* tw_w,
                           float norm, void* tmp, void* pair, int pair_dt, void* stream);
 int ocpg_lfm_spectrum_inv(const void* pair, int pair_dt, const float* coef, const float* high, const void* z_saved, float* coef_part, int N, int H,
                           int W, int C, const void* tw_h, const void* tw_w, float norm, void* tmp, const float* residual, float* out, void* stream);
 int ocpg_window_means3x3_fwd(const float* x, long long planes, int h, int w, int as_bf16, float* out, void* stream);
 int ocpg_window_means3x3_bwd(const float* gm, long long planes, int h, int w, float* dx, void* stream);
+/* The same on a channels-last map x [N, h, w, C] fp32 (round 4): part [N][ocpg_window_sums3x3_cl_bands(h)][C * 9] = window SUMS of a band of
+ * rows (the caller adds the bands and divides by (h-2)(w-2)); bwd_cl: dx [N, h, w, C] = the means' gradient (+ addend, dx's layout, or NULL). */
+int ocpg_window_sums3x3_cl_bands(int h);
+int ocpg_window_sums3x3_cl(const float* x, int N, int h, int w, int C, int as_bf16, float* part, void* stream);
+int ocpg_window_means3x3_bwd_cl(const float* gm, int N, int h, int w, int C, const float* addend, float* dx, void* stream);
 
 /* MSO mask refinement (reference models/decoder.py:14-46; called at models/ocpg.py:375-390 once per decoder layer): all of its
  * convolutions are 3x3 / padding 1 with <= 16 output channels per group, on CHANNELS-LAST maps (csrc/mso.hip).
@@ -484,6 +492,11 @@ int ocpg_groupnorm_cl_fwd(const void* x, int x_dtype, const float* gamma, const 
                           float* y, float* mean, float* rstd, float* work, void* stream);
 int ocpg_groupnorm_cl_bwd(const float* gy, const void* x, int x_dtype, const float* gamma, const float* mean, const float* rstd, long long N,
                           int HW, int C, int G, void* dx, float* part, float* work, void* stream);
+/* The same with y / gy channels-last as well ([N, HW, C] fp32; round 4: the LFM's own transforms, csrc/lfm_dft.hip, read that). */
+int ocpg_groupnorm_cl2cl_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, long long N, int HW, int C, int G, float eps,
+                             float* y, float* mean, float* rstd, float* work, void* stream);
+int ocpg_groupnorm_cl2cl_bwd(const float* gy, const void* x, int x_dtype, const float* gamma, const float* mean, const float* rstd, long long N,
+                             int HW, int C, int G, void* dx, float* part, float* work, void* stream);
 
 /* Backward of table[idx] ([T, H] -> [M, H]) for a STATIC index (the relative-position-bias lookup, models/video_swin_transformer.py:
  * 112-114,151-153): g [M, H] fp32, order [M] int64 = argsort(idx), seg [T + 1] int64 = CSR offsets of every table row's segment in

@@ -47,6 +47,9 @@ SIGNATURES = {
     "ocpg_gemm_import_picks": [_vp, ctypes.c_longlong],
     "ocpg_window_means3x3_fwd": [_vp, ctypes.c_longlong, _int, _int, _int, _vp, _vp],
     "ocpg_window_means3x3_bwd": [_vp, ctypes.c_longlong, _int, _int, _vp, _vp],
+    "ocpg_window_sums3x3_cl_bands": [_int],
+    "ocpg_window_sums3x3_cl": [_vp, _int, _int, _int, _int, _int, _vp, _vp],
+    "ocpg_window_means3x3_bwd_cl": [_vp, _int, _int, _int, _int, _vp, _vp, _vp],
     "ocpg_mso_conv3x3": [_vp, _int, _int, _vp, _int, _vp, _vp, _int, _vp, _int, _vp, _vp, _int] + [_int] * 6 + [_vp],
     "ocpg_mso_wgrad_rows": [_int] * 4,
     "ocpg_mso_wgrad": [_vp, _int, _int, _vp, _vp, _vp] + [_int] * 8 + [_vp],
@@ -58,6 +61,8 @@ SIGNATURES = {
     "ocpg_groupnorm_cl_work": [ctypes.c_longlong, _int, _int, _int],
     "ocpg_groupnorm_cl_fwd": [_vp, _int, _vp, _vp, ctypes.c_longlong, _int, _int, _int, ctypes.c_float, _vp, _vp, _vp, _vp, _vp],
     "ocpg_groupnorm_cl_bwd": [_vp, _vp, _int, _vp, _vp, _vp, ctypes.c_longlong, _int, _int, _int, _vp, _vp, _vp, _vp],
+    "ocpg_groupnorm_cl2cl_fwd": [_vp, _int, _vp, _vp, ctypes.c_longlong, _int, _int, _int, ctypes.c_float, _vp, _vp, _vp, _vp, _vp],
+    "ocpg_groupnorm_cl2cl_bwd": [_vp, _vp, _int, _vp, _vp, _vp, ctypes.c_longlong, _int, _int, _int, _vp, _vp, _vp, _vp],
     "ocpg_layernorm_fwd": [_vp, _int, _vp, _vp, ctypes.c_longlong, _int, ctypes.c_float, _vp, _int, _vp, _vp, _vp],
     "ocpg_layernorm_bwd": [_vp, _int, _vp, _int, _vp, _vp, _vp, ctypes.c_longlong, _int, _vp, _int, _vp, _vp, _vp],
     "ocpg_gather_rows_bwd": [_vp, _vp, _vp, _int, _int, _vp, _vp],
@@ -86,6 +91,7 @@ SIGNATURES = {
     "ocpg_grad_norm_clip_amp": [_vp] * 3 + [_int, ctypes.c_longlong, ctypes.c_float, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, _vp, _vp],
     "ocpg_adamw_step_amp": [_vp] * 8 + [_int, ctypes.c_longlong, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp],
     "ocpg_lfm_dft_supported": [_int, _int],
+    "ocpg_lfm_dft_split": [_int],
     "ocpg_lfm_spectrum_fwd": [_vp, _vp, _vp] + [_int] * 4 + [_vp, _vp, ctypes.c_float, _vp, _vp, _int, _vp],
     "ocpg_lfm_spectrum_inv": [_vp, _int, _vp, _vp, _vp, _vp] + [_int] * 4 + [_vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp],
     "ocpg_colsum_partials": [_vp, ctypes.c_longlong, _int, _int, _vp, _vp],
@@ -112,7 +118,7 @@ SIGNATURES = {
 
 # ---- optional live kernel timing (bench.py): HIP events on the launch stream around every library call ----------
 _TIMING = {"on": False, "events": []}
-_UNTIMED = ("ocpg_conv3x3_mfma_splits", "ocpg_gemm_set_tuning", "ocpg_gemm_export_picks", "ocpg_gemm_import_picks", "ocpg_colsum_blocks", "ocpg_mso_wgrad_rows", "ocpg_gemm_plans", "ocpg_gemm_tuned", "ocpg_gemm_tune_rejected", "ocpg_bias_relu_dropout_bwd_slots", "ocpg_dropout_add_ln_bwd_slots", "ocpg_groupnorm_cl_work")
+_UNTIMED = ("ocpg_window_sums3x3_cl_bands", "ocpg_lfm_dft_supported", "ocpg_lfm_dft_split", "ocpg_conv3x3_mfma_splits", "ocpg_gemm_set_tuning", "ocpg_gemm_export_picks", "ocpg_gemm_import_picks", "ocpg_colsum_blocks", "ocpg_mso_wgrad_rows", "ocpg_gemm_plans", "ocpg_gemm_tuned", "ocpg_gemm_tune_rejected", "ocpg_bias_relu_dropout_bwd_slots", "ocpg_dropout_add_ln_bwd_slots", "ocpg_groupnorm_cl_work")
 
 
 def enable_kernel_timing(on=True):

@@ -88,7 +88,7 @@ template <int K> __device__ __forceinline__ void block_sum(float (&v)[K], float 
 
 template <int DT>
 __global__ __launch_bounds__(NT) void gn_fwd(const void* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, int HW,
-                                             int C, int G, float eps, float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd) {
+                                             int C, int G, float eps, float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int ycl) {
   __shared__ float red[NT / 64][16];
   const int g = blockIdx.x % G;
   const long long n = blockIdx.x / G;
@@ -123,8 +123,15 @@ __global__ __launch_bounds__(NT) void gn_fwd(const void* __restrict__ x, const f
   float* yp = y + (n * C + g * D) * HW;
   for (int p = threadIdx.x; p < HW; p += NT) {
     load8<DT>(x, x0 + (long long)p * C, v);
+    if (ycl) {                                          // y channels-last too (round 4: the LFM's own transforms read that)
+      float o[D];
 #pragma unroll
-    for (int j = 0; j < D; ++j) yp[(long long)j * HW + p] = v[j] * a[j] + b[j];
+      for (int j = 0; j < D; ++j) o[j] = v[j] * a[j] + b[j];
+      store8<1>(y, x0 + (long long)p * C, o);
+    } else {
+#pragma unroll
+      for (int j = 0; j < D; ++j) yp[(long long)j * HW + p] = v[j] * a[j] + b[j];
+    }
   }
   if (threadIdx.x == 0) {
     mean[n * G + g] = mu;
@@ -135,7 +142,7 @@ __global__ __launch_bounds__(NT) void gn_fwd(const void* __restrict__ x, const f
 template <int DT>
 __global__ __launch_bounds__(NT) void gn_bwd(const float* __restrict__ gy, const void* __restrict__ x, const float* __restrict__ gamma,
                                              const float* __restrict__ mean, const float* __restrict__ rstd, int HW, int C, int G,
-                                             void* __restrict__ dx, float* __restrict__ part) {
+                                             void* __restrict__ dx, float* __restrict__ part, int ycl) {
   __shared__ float red[NT / 64][16];
   const int g = blockIdx.x % G;
   const long long n = blockIdx.x / G;
@@ -151,9 +158,11 @@ __global__ __launch_bounds__(NT) void gn_bwd(const float* __restrict__ gy, const
   for (int j = 0; j < 2 * D; ++j) acc[j] = 0.f;
   for (int p = threadIdx.x; p < HW; p += NT) {
     load8<DT>(x, x0 + (long long)p * C, v);
+    float gvv[D];
+    if (ycl) load8<1>(gy, x0 + (long long)p * C, gvv);
 #pragma unroll
     for (int j = 0; j < D; ++j) {
-      const float gv = gp[(long long)j * HW + p];
+      const float gv = ycl ? gvv[j] : gp[(long long)j * HW + p];
       acc[j] += gv * (v[j] - mu) * rs;
       acc[D + j] += gv;
     }
@@ -177,11 +186,12 @@ __global__ __launch_bounds__(NT) void gn_bwd(const float* __restrict__ gy, const
   cb *= inv;
   for (int p = threadIdx.x; p < HW; p += NT) {
     load8<DT>(x, x0 + (long long)p * C, v);
-    float o[D];
+    float o[D], gvv[D];
+    if (ycl) load8<1>(gy, x0 + (long long)p * C, gvv);
 #pragma unroll
     for (int j = 0; j < D; ++j) {
       const float xh = (v[j] - mu) * rs;
-      o[j] = rs * (gp[(long long)j * HW + p] * gm[j] - ca * xh - cb);
+      o[j] = rs * ((ycl ? gvv[j] : gp[(long long)j * HW + p]) * gm[j] - ca * xh - cb);
     }
     store8<DT>(dx, x0 + (long long)p * C, o);
   }
@@ -291,7 +301,7 @@ __device__ __forceinline__ void combine_stats(const float* __restrict__ stat, lo
 template <int DT>
 __global__ __launch_bounds__(NT) void gn_tile_apply(const void* __restrict__ x, const float* __restrict__ stat, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, int HW, float eps, float* __restrict__ y,
-                                                    float* __restrict__ mean, float* __restrict__ rstd) {
+                                                    float* __restrict__ mean, float* __restrict__ rstd, int ycl) {
   extern __shared__ __attribute__((aligned(16))) float lds[];          // [TC * TP] tile + 64 statistics
   float* sm = lds + TC * TP;
   const int tile = blockIdx.x, K = gridDim.x, oct = threadIdx.x & 31, sub = threadIdx.x >> 5, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -310,6 +320,17 @@ __global__ __launch_bounds__(NT) void gn_tile_apply(const void* __restrict__ x, 
   for (int j = 0; j < D; ++j) {
     a[j] = sm[32 + oct] * gamma[oct * D + j];
     b[j] = beta[oct * D + j] - sm[oct] * a[j];
+  }
+  if (ycl) {                                  // channels-last out: the thread's own pixel rows, no transpose
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int pl = it * 8 + sub;
+      float o[D];
+#pragma unroll
+      for (int j = 0; j < D; ++j) o[j] = v[it][j] * a[j] + b[j];
+      if (pl < npx) store8<1>(y, (n * HW + px0 + pl) * TC + oct * D, o);
+    }
+    return;
   }
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
@@ -339,17 +360,30 @@ __device__ __forceinline__ void load_plane_tile(const float* __restrict__ gy, lo
   }
 }
 
+// the same LDS image from a channels-last gy (rows beyond the map zero)
+__device__ __forceinline__ void load_cl_tile(const float* __restrict__ gy, long long n, int HW, int px0, int npx, int oct, int sub, float* lds) {
+  float g[8][D];
+  load_rows<1>(gy, n, HW, px0, npx, oct, sub, g);
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int pl = it * 8 + sub;
+#pragma unroll
+    for (int j = 0; j < D; ++j) lds[tidx(oct * D + j, pl)] = pl < npx ? g[it][j] : 0.f;
+  }
+}
+
 // P [N, K, 2, C]: per tile, per channel: sum gy xhat, sum gy
 template <int DT>
 __global__ __launch_bounds__(NT) void gn_tile_bwd_sums(const float* __restrict__ gy, const void* __restrict__ x, const float* __restrict__ mean,
-                                                       const float* __restrict__ rstd, int HW, float* __restrict__ P) {
+                                                       const float* __restrict__ rstd, int HW, float* __restrict__ P, int ycl) {
   extern __shared__ __attribute__((aligned(16))) float lds[];          // [TC * TP] tile, later reused as [4][32][16] reduction scratch
   const int tile = blockIdx.x, K = gridDim.x, oct = threadIdx.x & 31, sub = threadIdx.x >> 5;
   const long long n = blockIdx.y;
   const int px0 = tile * TP, npx = min(TP, HW - px0);
   float v[8][D];
   load_rows<DT>(x, n, HW, px0, npx, oct, sub, v);
-  load_plane_tile(gy, n, HW, px0, npx, lds);
+  if (ycl) load_cl_tile(gy, n, HW, px0, npx, oct, sub, lds);
+  else load_plane_tile(gy, n, HW, px0, npx, lds);
   const float mu = mean[n * TG + oct], rs = rstd[n * TG + oct];
   __syncthreads();
   float acc[2 * D];
@@ -385,7 +419,7 @@ __global__ __launch_bounds__(NT) void gn_tile_bwd_sums(const float* __restrict__
 template <int DT>
 __global__ __launch_bounds__(NT) void gn_tile_bwd_apply(const float* __restrict__ gy, const void* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ P,
-                                                        int HW, void* __restrict__ dx, float* __restrict__ part) {
+                                                        int HW, void* __restrict__ dx, float* __restrict__ part, int ycl) {
   extern __shared__ __attribute__((aligned(16))) float lds[];          // [TC * TP] tile + 64 group coefficients
   float* coef = lds + TC * TP;
   const int tile = blockIdx.x, K = gridDim.x, oct = threadIdx.x & 31, sub = threadIdx.x >> 5;
@@ -417,7 +451,8 @@ __global__ __launch_bounds__(NT) void gn_tile_bwd_apply(const float* __restrict_
   }
   float v[8][D];
   load_rows<DT>(x, n, HW, px0, npx, oct, sub, v);
-  load_plane_tile(gy, n, HW, px0, npx, lds);
+  if (ycl) load_cl_tile(gy, n, HW, px0, npx, oct, sub, lds);
+  else load_plane_tile(gy, n, HW, px0, npx, lds);
   const float mu = mean[n * TG + oct], rs = rstd[n * TG + oct];
   float gm[D];
 #pragma unroll
@@ -473,8 +508,8 @@ extern "C" long long ocpg_groupnorm_cl_work(long long N, int HW, int C, int G) {
   return N * ((HW + TP - 1) / TP) * 2 * TC;
 }
 
-extern "C" int ocpg_groupnorm_cl_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, long long N, int HW, int C, int G, float eps,
-                                     float* y, float* mean, float* rstd, float* work, void* stream) {
+static int gn_forward(const void* x, int x_dtype, const float* gamma, const float* beta, long long N, int HW, int C, int G, float eps,
+                      float* y, float* mean, float* rstd, float* work, void* stream, int ycl) {
   if (!x || !gamma || !beta || !y || !mean || !rstd) return -1;
   if (!shape_ok(N, HW, C, G, x_dtype)) return -2000;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -483,17 +518,26 @@ extern "C" int ocpg_groupnorm_cl_fwd(const void* x, int x_dtype, const float* ga
     const dim3 grid((unsigned)((HW + TP - 1) / TP), (unsigned)N), block(NT);
     GN_DISPATCH(gn_tile_stats, grid, block, 0, s, x, HW, work);
     GN_ALLOW_LDS(gn_tile_apply);
-    GN_DISPATCH(gn_tile_apply, grid, block, TILE_LDS, s, x, work, gamma, beta, HW, eps, y, mean, rstd);
+    GN_DISPATCH(gn_tile_apply, grid, block, TILE_LDS, s, x, work, gamma, beta, HW, eps, y, mean, rstd, ycl);
   } else {
     const dim3 grid((unsigned)(N * G)), block(NT);
-    GN_DISPATCH(gn_fwd, grid, block, 0, s, x, gamma, beta, HW, C, G, eps, y, mean, rstd);
+    GN_DISPATCH(gn_fwd, grid, block, 0, s, x, gamma, beta, HW, C, G, eps, y, mean, rstd, ycl);
   }
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
 
-extern "C" int ocpg_groupnorm_cl_bwd(const float* gy, const void* x, int x_dtype, const float* gamma, const float* mean, const float* rstd, long long N,
-                                     int HW, int C, int G, void* dx, float* part, float* work, void* stream) {
+extern "C" int ocpg_groupnorm_cl_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, long long N, int HW, int C, int G, float eps,
+                                     float* y, float* mean, float* rstd, float* work, void* stream) {
+  return gn_forward(x, x_dtype, gamma, beta, N, HW, C, G, eps, y, mean, rstd, work, stream, 0);
+}
+extern "C" int ocpg_groupnorm_cl2cl_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, long long N, int HW, int C, int G, float eps,
+                                        float* y, float* mean, float* rstd, float* work, void* stream) {
+  return gn_forward(x, x_dtype, gamma, beta, N, HW, C, G, eps, y, mean, rstd, work, stream, 1);
+}
+
+static int gn_backward(const float* gy, const void* x, int x_dtype, const float* gamma, const float* mean, const float* rstd, long long N,
+                       int HW, int C, int G, void* dx, float* part, float* work, void* stream, int ycl) {
   if (!gy || !x || !gamma || !mean || !rstd || !dx || !part) return -1;
   if (!shape_ok(N, HW, C, G, x_dtype)) return -2000;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -501,13 +545,22 @@ extern "C" int ocpg_groupnorm_cl_bwd(const float* gy, const void* x, int x_dtype
     if (!work) return -1;
     const dim3 grid((unsigned)((HW + TP - 1) / TP), (unsigned)N), block(NT);
     GN_ALLOW_LDS(gn_tile_bwd_sums);
-    GN_DISPATCH(gn_tile_bwd_sums, grid, block, TILE_LDS, s, gy, x, mean, rstd, HW, work);
+    GN_DISPATCH(gn_tile_bwd_sums, grid, block, TILE_LDS, s, gy, x, mean, rstd, HW, work, ycl);
     GN_ALLOW_LDS(gn_tile_bwd_apply);
-    GN_DISPATCH(gn_tile_bwd_apply, grid, block, TILE_LDS, s, gy, x, gamma, mean, rstd, work, HW, dx, part);
+    GN_DISPATCH(gn_tile_bwd_apply, grid, block, TILE_LDS, s, gy, x, gamma, mean, rstd, work, HW, dx, part, ycl);
   } else {
     const dim3 grid((unsigned)(N * G)), block(NT);
-    GN_DISPATCH(gn_bwd, grid, block, 0, s, gy, x, gamma, mean, rstd, HW, C, G, dx, part);
+    GN_DISPATCH(gn_bwd, grid, block, 0, s, gy, x, gamma, mean, rstd, HW, C, G, dx, part, ycl);
   }
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
+}
+
+extern "C" int ocpg_groupnorm_cl_bwd(const float* gy, const void* x, int x_dtype, const float* gamma, const float* mean, const float* rstd, long long N,
+                                     int HW, int C, int G, void* dx, float* part, float* work, void* stream) {
+  return gn_backward(gy, x, x_dtype, gamma, mean, rstd, N, HW, C, G, dx, part, work, stream, 0);
+}
+extern "C" int ocpg_groupnorm_cl2cl_bwd(const float* gy, const void* x, int x_dtype, const float* gamma, const float* mean, const float* rstd, long long N,
+                                        int HW, int C, int G, void* dx, float* part, float* work, void* stream) {
+  return gn_backward(gy, x, x_dtype, gamma, mean, rstd, N, HW, C, G, dx, part, work, stream, 1);
 }

@@ -35,6 +35,7 @@
 namespace {
 
 constexpr int MAXR = 16, NT = 256, NW = NT / 64, CH = 64;
+constexpr int U = 8;                    // global loads of a line in flight per thread
 
 struct Split { int L, L1, L2; };
 
@@ -56,60 +57,83 @@ template <> __device__ __forceinline__ void stf<__half>(__half* p, float v) { *p
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
-// tw[k] = exp(-2 pi i k / L) (forward); INV conjugates.  Element j of the line sits at tile[j * CH + lane] on entry; output element
-// k sits at slot (k % L1) * L2 + k / L1 on exit (slot_of).  kmax: only outputs k <= kmax are needed (half spectrum of a real line).
-template <bool INV>
+// One Cooley-Tukey step: nb small DFTs of length R, in place.  Batch b reads slots b * bstride + j * jstride (j < R) and leaves output
+// k in slot b * bstride + k * jstride.  twR = the R-point DFT matrix W_R^(jk) at [k * R + j]: the twiddles of one output are ONE row of
+// it, R consecutive float2 with compile-time offsets = a couple of wide scalar loads (wave-uniform address), then R complex
+// multiply-adds.  (Indexing one table of W_L powers with (L / R) j k mod L instead cost ~14 scalar instructions per twiddle -- 64-bit
+// address arithmetic, compare / select -- against its 4 FMAs: 117 us per launch at 48 x 80 where the arithmetic is 30.)
+// STEP1: output k of batch b is also multiplied by W_L^(b k) (twL) and the inputs may be real (REAL_IN: imaginary parts are zero, half
+// the products); step 2 (STEP1 false): batch b = k1, output k = k2 is spectrum element k1 + L1 k2, skipped past kmax; REAL_OUT: only
+// the real part is wanted.
+template <int R, bool INV, bool STEP1, bool REAL_IN, bool REAL_OUT>
+__device__ __forceinline__ void dft_batch(float2* __restrict__ tile, const float2* __restrict__ twR, const float2* __restrict__ twL, int nb, int bstride,
+                                          int jstride, int L1, int kmax, int lane, int wave) {
+  for (int b = wave; b < nb; b += NW) {
+    float2 r[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) r[j] = tile[(b * bstride + j * jstride) * CH + lane];
+    // (outputs go straight back to the batch's own slots: its inputs are all in registers by now)
+#pragma unroll 2
+    for (int k = 0; k < R; ++k) {
+      if (!STEP1 && b + L1 * k > kmax) break;
+      const float2* __restrict__ row = twR + k * R;
+      float2 t[R];
+#pragma unroll
+      for (int j = 1; j < R; ++j) t[j] = row[j];
+      float2 acc = REAL_IN ? make_float2(r[0].x, 0.f) : r[0];
+#pragma unroll
+      for (int j = 1; j < R; ++j) {
+        const float ty = INV ? -t[j].y : t[j].y;
+        acc.x += r[j].x * t[j].x;
+        if (!REAL_OUT) acc.y += r[j].x * ty;
+        if (!REAL_IN) {
+          acc.x -= r[j].y * ty;
+          if (!REAL_OUT) acc.y += r[j].y * t[j].x;
+        }
+      }
+      if (STEP1 && k > 0) {
+        float2 w = twL[b * k];                  // b < L2, k < L1: b k < L
+        if (INV) w.y = -w.y;
+        acc = cmul(acc, w);
+      }
+      tile[(b * bstride + k * jstride) * CH + lane] = acc;
+    }
+  }
+}
+
+#define OCPG_DFT_CASE(R_) case R_: dft_batch<R_, INV, STEP1, REAL_IN, REAL_OUT>(tile, twR, twL, nb, bstride, jstride, L1, kmax, lane, wave); break;
+template <bool INV, bool STEP1, bool REAL_IN, bool REAL_OUT>
+__device__ __forceinline__ void dft_step(int R, float2* __restrict__ tile, const float2* __restrict__ twR, const float2* __restrict__ twL, int nb, int bstride,
+                                         int jstride, int L1, int kmax, int lane, int wave) {
+  switch (R) {
+    OCPG_DFT_CASE(2) OCPG_DFT_CASE(3) OCPG_DFT_CASE(4) OCPG_DFT_CASE(5) OCPG_DFT_CASE(6) OCPG_DFT_CASE(7) OCPG_DFT_CASE(8) OCPG_DFT_CASE(9)
+    OCPG_DFT_CASE(10) OCPG_DFT_CASE(11) OCPG_DFT_CASE(12) OCPG_DFT_CASE(13) OCPG_DFT_CASE(14) OCPG_DFT_CASE(15) OCPG_DFT_CASE(16)
+    default: break;                      // R == 1: the identity
+  }
+}
+#undef OCPG_DFT_CASE
+
+// tw: the tables of one length L (float2; forward sign, INV conjugates): [0, L) W_L^m = exp(-2 pi i m / L); [L, L + L1^2) the L1-point
+// DFT matrix W_L1^(jk) at k * L1 + j; then the L2-point one (ocpg_lfm_dft_split gives L1, L2; ops/functions/spectral_func.py builds
+// them in fp64).  Element j of the line sits at tile[j * CH + lane] on entry; output element k sits at slot (k % L1) * L2 + k / L1 on
+// exit (slot_of).  kmax: only outputs k <= kmax are needed (half spectrum of a real line).
+template <bool INV, bool REAL_IN = false, bool REAL_OUT = false>
 __device__ __forceinline__ void line_dft(float2* __restrict__ tile, const Split s, const float2* __restrict__ tw, int lane, int wave, int kmax) {
   const int L = s.L, L1 = s.L1, L2 = s.L2;
+#ifdef DFT_CUT_COMPUTE
+  __syncthreads();
+  return;
+#endif
+  const float2* __restrict__ tw1 = tw + L;
+  const float2* __restrict__ tw2 = tw1 + L1 * L1;
   if (L1 > 1) {
-    for (int j2 = wave; j2 < L2; j2 += NW) {
-      float2 r[MAXR];
-#pragma unroll
-      for (int j1 = 0; j1 < MAXR; ++j1)
-        if (j1 < L1) r[j1] = tile[(j1 * L2 + j2) * CH + lane];
-      for (int k1 = 0; k1 < L1; ++k1) {
-        float2 acc = r[0];
-        const int st = (L2 * k1) % L;          // W_L1^(j1 k1) = W_L^(L2 j1 k1)
-        int ti = 0;
-#pragma unroll
-        for (int j1 = 1; j1 < MAXR; ++j1)
-          if (j1 < L1) {
-            ti += st;
-            if (ti >= L) ti -= L;
-            float2 t = tw[ti];
-            if (INV) t.y = -t.y;
-            acc.x += r[j1].x * t.x - r[j1].y * t.y;
-            acc.y += r[j1].x * t.y + r[j1].y * t.x;
-          }
-        float2 t = tw[(j2 * k1) % L];
-        if (INV) t.y = -t.y;
-        tile[(k1 * L2 + j2) * CH + lane] = cmul(acc, t);
-      }
-    }
+    // step 1: L2 column DFTs of length L1 over slots j1 * L2 + j2, then the twiddle W_L^(j2 k1)
+    dft_step<INV, true, REAL_IN, false>(L1, tile, tw1, tw, L2, 1, L2, L1, kmax, lane, wave);
     __syncthreads();
-  }
-  for (int k1 = wave; k1 < L1; k1 += NW) {
-    float2 r[MAXR];
-#pragma unroll
-    for (int j2 = 0; j2 < MAXR; ++j2)
-      if (j2 < L2) r[j2] = tile[(k1 * L2 + j2) * CH + lane];
-    for (int k2 = 0; k2 < L2; ++k2) {
-      if (k1 + L1 * k2 > kmax) break;
-      float2 acc = r[0];
-      const int st = (L1 * k2) % L;            // W_L2^(j2 k2) = W_L^(L1 j2 k2)
-      int ti = 0;
-#pragma unroll
-      for (int j2 = 1; j2 < MAXR; ++j2)
-        if (j2 < L2) {
-          ti += st;
-          if (ti >= L) ti -= L;
-          float2 t = tw[ti];
-          if (INV) t.y = -t.y;
-          acc.x += r[j2].x * t.x - r[j2].y * t.y;
-          acc.y += r[j2].x * t.y + r[j2].y * t.x;
-        }
-      tile[(k1 * L2 + k2) * CH + lane] = acc;
-    }
+    // step 2: L1 row DFTs of length L2 over slots k1 * L2 + j2
+    dft_step<INV, false, false, REAL_OUT>(L2, tile, tw2, tw, L1, L2, 1, L1, kmax, lane, wave);
+  } else {
+    dft_step<INV, false, REAL_IN, REAL_OUT>(L2, tile, tw2, tw, 1, L2, 1, 1, kmax, lane, wave);
   }
   __syncthreads();
 }
@@ -124,9 +148,22 @@ __global__ __launch_bounds__(NT) void rows_fwd(const float* __restrict__ x, int 
   const int c = blockIdx.y * CH + lane;
   const bool ok = c < C;
   const int Wh = W / 2 + 1;
-  for (int j = wave; j < W; j += NW) tile[j * CH + lane] = make_float2(ok ? x[(line * W + j) * C + c] : 0.f, 0.f);
+  // (loads in batches of U: a load + LDS store per iteration serialises one HBM round trip per element of the line)
+  for (int j0 = wave; j0 < W; j0 += NW * U) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + u * NW;
+      v[u] = (ok && j < W) ? x[(line * W + j) * C + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + u * NW;
+      if (j < W) tile[j * CH + lane] = make_float2(v[u], 0.f);
+    }
+  }
   __syncthreads();
-  line_dft<false>(tile, s, tw, lane, wave, W / 2);
+  line_dft<false, true, false>(tile, s, tw, lane, wave, W / 2);
   if (ok)
     for (int v = wave; v < Wh; v += NW) T[(line * Wh + v) * C + c] = tile[slot_of(s, v) * CH + lane];
 }
@@ -141,7 +178,19 @@ __global__ __launch_bounds__(NT) void cols_fwd(const float2* __restrict__ T, con
   const int n = blockIdx.x / Wh, v = blockIdx.x - n * Wh;
   const int c = blockIdx.y * CH + lane;
   const bool ok = c < C;
-  for (int y = wave; y < H; y += NW) tile[y * CH + lane] = ok ? T[(((long long)n * H + y) * Wh + v) * C + c] : make_float2(0.f, 0.f);
+  for (int y0 = wave; y0 < H; y0 += NW * U) {
+    float2 q[U];
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+      const int y = y0 + i * NW;
+      q[i] = (ok && y < H) ? T[(((long long)n * H + y) * Wh + v) * C + c] : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+      const int y = y0 + i * NW;
+      if (y < H) tile[y * CH + lane] = q[i];
+    }
+  }
   __syncthreads();
   line_dft<false>(tile, s, tw, lane, wave, H);
   if (!ok) return;
@@ -179,23 +228,37 @@ __global__ __launch_bounds__(NT) void cols_inv(const P* __restrict__ pair, const
   const float cf = coef ? coef[n] : 0.f;
   const int vm = v ? W - v : 0;
   float dsum = 0.f;
-  for (int u = wave; u < H; u += NW) {
-    float2 h = make_float2(0.f, 0.f);
-    if (ok) {
-      const int um = u ? H - u : 0;
-      const long long ia = (((long long)n * H + u) * W + v) * 2 * C + c, ib = (((long long)n * H + um) * W + vm) * 2 * C + c;
-      const float ha = coef ? high[u * W + v] : 0.f, hb = coef ? high[um * W + vm] : 0.f;
-      const float ga = 1.f - cf * ha, gb = 1.f - cf * hb;
-      const float ar = ldf(pair + ia), ai = ldf(pair + ia + C), br = ldf(pair + ib), bi = ldf(pair + ib + C);
-      h = make_float2(0.5f * (ar * ga + br * gb), 0.5f * (ai * ga - bi * gb));
-      if (part) {
-        // d/dcoef of S * (1 - coef * high): -high * (g_re S_re + g_im S_im), with S = z / gate from the saved gated spectrum (a gate
-        // of exactly 0 -- coef == 1.0f at the one frequency where high == 1 -- has lost S: that single term is dropped)
-        if (ga != 0.f) dsum -= ha * (ar * ldf(zs + ia) + ai * ldf(zs + ia + C)) / ga;
-        if (vm != v && gb != 0.f) dsum -= hb * (br * ldf(zs + ib) + bi * ldf(zs + ib + C)) / gb;
+  constexpr int UI = 4;
+  for (int u0 = wave; u0 < H; u0 += NW * UI) {
+    float ar[UI], ai[UI], br[UI], bi[UI], za[UI], zb[UI], zc[UI], zd[UI], ha[UI], hb[UI];
+#pragma unroll
+    for (int i = 0; i < UI; ++i) {
+      const int u = u0 + i * NW;
+      ar[i] = ai[i] = br[i] = bi[i] = za[i] = zb[i] = zc[i] = zd[i] = ha[i] = hb[i] = 0.f;
+      if (ok && u < H) {
+        const int um = u ? H - u : 0;
+        const long long ia = (((long long)n * H + u) * W + v) * 2 * C + c, ib = (((long long)n * H + um) * W + vm) * 2 * C + c;
+        ar[i] = ldf(pair + ia), ai[i] = ldf(pair + ia + C), br[i] = ldf(pair + ib), bi[i] = ldf(pair + ib + C);
+        if (coef) ha[i] = high[u * W + v], hb[i] = high[um * W + vm];
+        if (part) {
+          za[i] = ldf(zs + ia), zb[i] = ldf(zs + ia + C);
+          if (vm != v) zc[i] = ldf(zs + ib), zd[i] = ldf(zs + ib + C);
+        }
       }
     }
-    tile[u * CH + lane] = h;
+#pragma unroll
+    for (int i = 0; i < UI; ++i) {
+      const int u = u0 + i * NW;
+      if (u >= H) continue;
+      const float ga = 1.f - cf * ha[i], gb = 1.f - cf * hb[i];
+      // d/dcoef of S * (1 - coef * high): -high * (g_re S_re + g_im S_im), with S = z / gate from the saved gated spectrum (a gate
+      // of exactly 0 -- coef == 1.0f at the one frequency where high == 1 -- has lost S: that single term is dropped)
+      if (part && ok) {
+        if (ga != 0.f) dsum -= ha[i] * (ar[i] * za[i] + ai[i] * zb[i]) / ga;
+        if (vm != v && gb != 0.f) dsum -= hb[i] * (br[i] * zc[i] + bi[i] * zd[i]) / gb;
+      }
+      tile[u * CH + lane] = make_float2(0.5f * (ar[i] * ga + br[i] * gb), 0.5f * (ai[i] * ga - bi[i] * gb));
+    }
   }
   __syncthreads();
   line_dft<true>(tile, s, tw, lane, wave, H);
@@ -223,20 +286,35 @@ __global__ __launch_bounds__(NT) void rows_inv(const float2* __restrict__ T, int
   const int c = blockIdx.y * CH + lane;
   const bool ok = c < C;
   const int Wh = W / 2 + 1;
-  for (int v = wave; v < W; v += NW) {
-    float2 t = make_float2(0.f, 0.f);
-    if (ok) {
-      if (v < Wh) t = T[(line * Wh + v) * C + c];
-      else { t = T[(line * Wh + (W - v)) * C + c]; t.y = -t.y; }
+  for (int v0 = wave; v0 < W; v0 += NW * U) {
+    float2 q[U];
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+      const int v = v0 + i * NW;
+      q[i] = make_float2(0.f, 0.f);
+      if (ok && v < W) q[i] = T[(line * Wh + (v < Wh ? v : W - v)) * C + c];
     }
-    tile[v * CH + lane] = t;
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+      const int v = v0 + i * NW;
+      if (v < W) tile[v * CH + lane] = make_float2(q[i].x, v < Wh ? q[i].y : -q[i].y);
+    }
   }
   __syncthreads();
-  line_dft<true>(tile, s, tw, lane, wave, W);
+  line_dft<true, false, true>(tile, s, tw, lane, wave, W);
   if (ok)
-    for (int j = wave; j < W; j += NW) {
-      const long long i = (line * W + j) * C + c;
-      out[i] = norm * tile[slot_of(s, j) * CH + lane].x + (residual ? residual[i] : 0.f);
+    for (int j0 = wave; j0 < W; j0 += NW * U) {
+      float rs[U];
+#pragma unroll
+      for (int i = 0; i < U; ++i) {
+        const int j = j0 + i * NW;
+        rs[i] = (residual && j < W) ? residual[(line * W + j) * C + c] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < U; ++i) {
+        const int j = j0 + i * NW;
+        if (j < W) out[(line * W + j) * C + c] = norm * tile[slot_of(s, j) * CH + lane].x + rs[i];
+      }
     }
 }
 
@@ -248,6 +326,12 @@ inline int status() {
 }  // namespace
 
 extern "C" {
+
+int ocpg_lfm_dft_split(int L) {                  /* L1 * 256 + L2 of the line transform of length L; 0: not served */
+  if (L < 1) return 0;
+  const Split s = split_of(L);
+  return s.L1 ? s.L1 * 256 + s.L2 : 0;
+}
 
 int ocpg_lfm_dft_supported(int H, int W) {
   if (H < 1 || W < 1) return 0;

@@ -37,6 +37,7 @@ from .postprocessors import build_postprocessors
 from .resample import bicubic_resize, bilinear_resize, nearest_upsample
 
 MATMUL_BILINEAR = True       # A/B switch: bilinear resampling as two matrix products (no atomics backward)
+CL_FUSE = os.environ.get("OCPG_CL_FUSE", "1") != "0"         # A/B switch: the fused visual map leaves the text gate in channels-last memory
 LS_FEAT_N16 = os.environ.get("OCPG_LS_FEAT_N16", "1") != "0"     # A/B switch: ls_feat_viz (3x3, 256 -> 8) by csrc/mso.hip's <= 16-output kernels
 from .segmentation import VisionLanguageFusionModule
 from .text_encoder.text_encoder import FeatureResizer, PrecomputedText, TextEncoder
@@ -202,7 +203,12 @@ class OCPG(nn.Module):
         src, high_filter = self.input_fft[l](src, high_filter)
         vis = src.view(b, t, c, h, w).permute(1, 3, 4, 0, 2)                      # t h w b c
         vis = self.fusion_module(visual=vis, text=text_words, text_key_padding_mask=text_pad, text_pos=text_pos, visual_pos=None)
-        src = vis.view(t, h, w, b, c).permute(3, 0, 4, 1, 2).reshape(b * t, c, h, w)
+        if CL_FUSE and vis.is_cuda:
+            # [(b t), c, h, w] in channels-last memory: ONE copy out of the token-major layout (the LFM's transforms and the transformer's
+            # flatten(2).transpose(1, 2) both read channels-last; NCHW here cost a second transposing copy in each of them)
+            src = vis.view(t, h, w, b, c).permute(3, 0, 1, 2, 4).reshape(b * t, h, w, c).permute(0, 3, 1, 2)
+        else:
+            src = vis.view(t, h, w, b, c).permute(3, 0, 4, 1, 2).reshape(b * t, c, h, w)
         return self.input_fft_post[l](src, high_filter)
 
     def forward(self, samples, captions, targets):

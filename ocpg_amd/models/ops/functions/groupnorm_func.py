@@ -1,5 +1,7 @@
 """Autograd binding of csrc/groupnorm.hip: the GroupNorm behind the input projections (reference models/ocpg.py:108-119), reading the
 channels-last map the projection GEMM wrote and writing the fp32 planes the LFM's FFTs read -- one launch each way."""
+import os
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -16,19 +18,24 @@ def _scratch(x, groups):
     return torch.empty(words, dtype=torch.float32, device=x.device) if words > 0 else None
 
 
+CL_OUT = os.environ.get("OCPG_GN_CL_OUT", "1") != "0"     # A/B switch: the fp32 output channels-last as well (the LFM's own transforms read that; "0": planes, as rocFFT wanted)
+
+
 class GroupNormCLFunction(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, groups, eps):
+    def forward(ctx, x, weight, bias, groups, eps, cl_out=False):
         n, c, h, w = x.shape
-        y = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+        y = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2) if cl_out else \
+            torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
         mean = torch.empty((n, groups), dtype=torch.float32, device=x.device)
         rstd = torch.empty((n, groups), dtype=torch.float32, device=x.device)
         work = _scratch(x, groups)
-        check(lib().ocpg_groupnorm_cl_fwd(x.data_ptr(), _CODE[x.dtype], weight.data_ptr(), bias.data_ptr(), n, h * w, c, groups, float(eps),
+        fwd = lib().ocpg_groupnorm_cl2cl_fwd if cl_out else lib().ocpg_groupnorm_cl_fwd
+        check(fwd(x.data_ptr(), _CODE[x.dtype], weight.data_ptr(), bias.data_ptr(), n, h * w, c, groups, float(eps),
                                           y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), 0 if work is None else work.data_ptr(),
                                           torch.cuda.current_stream().cuda_stream), "ocpg_groupnorm_cl_fwd")
         ctx.save_for_backward(x, weight, mean, rstd)
-        ctx.groups = groups
+        ctx.groups, ctx.cl_out = groups, cl_out
         return y
 
     @staticmethod
@@ -36,15 +43,20 @@ class GroupNormCLFunction(Function):
     def backward(ctx, gy):
         x, weight, mean, rstd = ctx.saved_tensors
         n, c, h, w = x.shape
-        gy = gy.float().contiguous()
+        if ctx.cl_out:
+            gy = gy.float().permute(0, 2, 3, 1)
+            gy = gy if gy.is_contiguous() else gy.contiguous()
+        else:
+            gy = gy.float().contiguous()
         dx = torch.empty_like(x)                       # preserves the channels-last strides
         part = torch.empty((n, 2, c), dtype=torch.float32, device=x.device)
         work = _scratch(x, ctx.groups)
-        check(lib().ocpg_groupnorm_cl_bwd(gy.data_ptr(), x.data_ptr(), _CODE[x.dtype], weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), n,
+        bwd = lib().ocpg_groupnorm_cl2cl_bwd if ctx.cl_out else lib().ocpg_groupnorm_cl_bwd
+        check(bwd(gy.data_ptr(), x.data_ptr(), _CODE[x.dtype], weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), n,
                                           h * w, c, ctx.groups, dx.data_ptr(), part.data_ptr(), 0 if work is None else work.data_ptr(),
                                           torch.cuda.current_stream().cuda_stream), "ocpg_groupnorm_cl_bwd")
         dgb = part.sum(0)                              # one reduction for dgamma and dbeta
-        return dx, dgb[0], dgb[1], None, None
+        return dx, dgb[0], dgb[1], None, None, None
 
 
 def eligible(x, module):
@@ -60,5 +72,5 @@ class GroupNorm(torch.nn.GroupNorm):
 
     def forward(self, x):
         if eligible(x, self):
-            return GroupNormCLFunction.apply(x, self.weight, self.bias, self.num_groups, self.eps)
+            return GroupNormCLFunction.apply(x, self.weight, self.bias, self.num_groups, self.eps, CL_OUT)
         return super().forward(x)

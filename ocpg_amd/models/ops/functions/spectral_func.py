@@ -60,10 +60,37 @@ class WindowMeans3x3(Function):
         return dx, None
 
 
+class WindowMeans3x3CL(Function):
+    """WindowMeans3x3 for x [N,C,h,w] fp32 in CHANNELS-LAST memory (round 4), same result [N, C*9]."""
+
+    @staticmethod
+    def forward(ctx, x, as_bf16):
+        xs = x.permute(0, 2, 3, 1)
+        assert xs.is_contiguous() and xs.dtype == torch.float32
+        n, h, w, c = xs.shape
+        bands = int(lib().ocpg_window_sums3x3_cl_bands(h))
+        part = torch.empty((n, bands, c * 9), dtype=torch.float32, device=x.device)
+        check(lib().ocpg_window_sums3x3_cl(xs.data_ptr(), n, h, w, c, int(as_bf16), part.data_ptr(), torch.cuda.current_stream().cuda_stream),
+              "ocpg_window_sums3x3_cl")
+        ctx.shape = (n, c, h, w)
+        return part.sum(1) * (1.0 / ((h - 2) * (w - 2)))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gm):
+        n, c, h, w = ctx.shape
+        gm = gm.float().contiguous()
+        dx = torch.empty((n, h, w, c), dtype=torch.float32, device=gm.device)
+        check(lib().ocpg_window_means3x3_bwd_cl(gm.data_ptr(), n, h, w, c, None, dx.data_ptr(), torch.cuda.current_stream().cuda_stream),
+              "ocpg_window_means3x3_bwd_cl")
+        return dx.permute(0, 3, 1, 2), None
+
+
 def conv3x3_valid_spatial_mean(x, weight, bias, as_bf16):
     """== F.conv2d(x, weight, bias).mean(dim=(2, 3)) for a 3x3 valid convolution, without the convolution.  `weight` is the copy
     the convolution would have used (bf16 under autocast): the products are the same, only the summation order differs."""
-    m = WindowMeans3x3.apply(x, as_bf16)
+    cl = x.dim() == 4 and x.dtype == torch.float32 and x.shape[1] > 1 and x.permute(0, 2, 3, 1).is_contiguous() and x.shape[0] <= 65535
+    m = WindowMeans3x3CL.apply(x, as_bf16) if cl else WindowMeans3x3.apply(x, as_bf16)
     with torch.autocast(device_type=x.device.type, enabled=False):
         return torch.nn.functional.linear(m, weight.float().flatten(1), None if bias is None else bias.float())
 
@@ -169,12 +196,23 @@ def dft_supported(h, w):
 
 
 def _twiddles(n, device):
-    """exp(-2 pi i k / n), k < n, formed in fp64: float2 [n]"""
+    """The tables of a line transform of length n (include/ocpg_hip.h): exp(-2 pi i m / n), then the L1- and the L2-point DFT matrices,
+    formed in fp64: float2 [n + L1^2 + L2^2]"""
     from ....util.misc import memo
 
     def make():
-        a = torch.arange(n, dtype=torch.float64) * (-2.0 * torch.pi / n)
-        return torch.stack([a.cos(), a.sin()], -1).float().to(device)
+        code = int(lib().ocpg_lfm_dft_split(int(n)))
+        assert code, f"length {n} is not served by csrc/lfm_dft.hip"
+        l1, l2 = code >> 8, code & 255
+
+        def angles(idx, m):
+            a = idx.to(torch.float64) * (-2.0 * torch.pi / m)
+            return torch.stack([a.cos(), a.sin()], -1)
+        parts = [angles(torch.arange(n), n)]
+        for r in (l1, l2):
+            k = torch.arange(r)
+            parts.append(angles((k[:, None] * k[None, :]).remainder(r).flatten(), r))
+        return torch.cat(parts).float().contiguous().to(device)
     return memo("lfm_tw", n, device, make)
 
 

@@ -345,12 +345,16 @@ def test_small_linear_kernel(dev, xdt, r, cin, cout, bias, relu):
 
 @pytest.mark.parametrize("xdt", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("n,c,h,w", [(10, 256, 45, 80), (2, 256, 50, 33), (1, 256, 25, 61), (3, 256, 23, 40), (2, 256, 6, 10), (1, 64, 1, 3), (2, 512, 17, 15)])
-def test_groupnorm_channels_last_kernel(dev, xdt, n, c, h, w):
-    """csrc/groupnorm.hip (channels-last map in its own dtype -> fp32 planes, one launch each way) == F.group_norm in fp32 on the same
+@pytest.mark.parametrize("cl_out", [False, True])
+def test_groupnorm_channels_last_kernel(dev, xdt, n, c, h, w, cl_out, monkeypatch):
+    """csrc/groupnorm.hip (channels-last map in its own dtype -> fp32 planes, or (cl_out, round 4) -> an fp32 channels-last map, with a
+    non-contiguous gradient coming back; one launch each way) == F.group_norm in fp32 on the same
     stored values (what autocast computes for the reference's GroupNorm(32, 256), models/ocpg.py:108-119) and its autograd backward:
     y, dgamma, dbeta to fp32 rounding; dx to fp32 rounding for fp32 maps and to one ulp of the map's dtype otherwise.  Maps of >= 1 500
     pixels take the pixel-tiled kernels (two launches each way, ragged last tile included), smaller ones the one-launch kernels."""
+    from ocpg_amd.models.ops.functions import groupnorm_func
     from ocpg_amd.models.ops.functions.groupnorm_func import GroupNorm, eligible
+    monkeypatch.setattr(groupnorm_func, "CL_OUT", cl_out)
     gen = torch.Generator(device=dev).manual_seed(n * 1000 + c + h)
     gn = GroupNorm(c // 8, c).to(dev)
     with torch.no_grad():
@@ -365,7 +369,7 @@ def test_groupnorm_channels_last_kernel(dev, xdt, n, c, h, w):
         if mine:
             assert eligible(xi, gn)
             y = gn(xi)
-            assert y.is_contiguous() and y.dtype == torch.float32
+            assert (y.permute(0, 2, 3, 1) if cl_out else y).is_contiguous() and y.dtype == torch.float32 and y.shape == (n, c, h, w)
         else:
             y = torch.nn.functional.group_norm(xi.float(), gn.num_groups, gn.weight, gn.bias, gn.eps)
         (y * go).sum().backward()
