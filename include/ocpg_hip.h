@@ -468,6 +468,11 @@ int ocpg_bilinear_nhwc_bwd(const float* gout, int NB, int H, int W, int C, int H
 int ocpg_small_linear_fwd(const void* x, int x_f32, const void* w, const void* b, int R, int Cin, int Cout, int relu, void* y, void* stream);
 int ocpg_small_linear_bwd(const void* gy, int gy_f32, const void* x, int x_f32, const void* w, const void* y_relu, int R, int Cin, int Cout,
                           void* gx, void* gw, void* gb, void* stream);
+/* The same for the fp32 islands (MSDeformAttn's projections over the decoder's few query rows run with autocast disabled, reference
+ * models/deformable_transformer.py:329-332): x / w / b / y and every gradient fp32, exact fp32 products on the matrix cores
+ * (csrc/small_linear_f32.hip).  gx NULL: not needed; gb NULL: no bias.  Cin % 64 != 0 or R > 4096: -2000. */
+int ocpg_small_linear_f32_fwd(const float* x, const float* w, const float* b, int R, int Cin, int Cout, float* y, void* stream);
+int ocpg_small_linear_f32_bwd(const float* gy, const float* x, const float* w, int R, int Cin, int Cout, float* gx, float* gw, float* gb, void* stream);
 
 /* nn.LayerNorm over the last axis of a token matrix with low-precision input / output (Video-Swin blocks: norm1, norm2,
  * PatchMerging.norm -- models/video_swin_transformer.py:194,201,225): x [rows, C] with storage code x_f32 (1 fp32, 0 bf16, 2 fp16),

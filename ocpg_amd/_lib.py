@@ -57,6 +57,8 @@ SIGNATURES = {
     "ocpg_bilinear_nhwc_bwd": [_vp] + [_int] * 6 + [_vp, _vp],
     "ocpg_small_linear_fwd": [_vp, _int, _vp, _vp, _int, _int, _int, _int, _vp, _vp],
     "ocpg_small_linear_bwd": [_vp, _int, _vp, _int, _vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp],
+    "ocpg_small_linear_f32_fwd": [_vp, _vp, _vp, _int, _int, _int, _vp, _vp],
+    "ocpg_small_linear_f32_bwd": [_vp, _vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp],
     "ocpg_layernorm_blocks": [ctypes.c_longlong],
     "ocpg_groupnorm_cl_work": [ctypes.c_longlong, _int, _int, _int],
     "ocpg_groupnorm_cl_fwd": [_vp, _int, _vp, _vp, ctypes.c_longlong, _int, _int, _int, ctypes.c_float, _vp, _vp, _vp, _vp, _vp],

@@ -431,6 +431,7 @@ class TokenLinearFunction(torch.autograd.Function):
         return gx, gw, gb
 
 
+SMALL_LINEAR_F32 = os.environ.get("OCPG_SMALL_LINEAR_F32", "1") != "0"     # A/B switch: the fp32 islands' few-row Linears too (csrc/small_linear_f32.hip)
 SMALL_LINEAR = os.environ.get("OCPG_SMALL_LINEAR", "1") != "0"     # A/B switch: few-row Linears as one launch each way (csrc/small_linear.hip)
 
 
@@ -477,6 +478,50 @@ class SmallLinearFunction(torch.autograd.Function):
         return (None if gx is None else gx.view(ctx.x_shape)), gw, gb, None
 
 
+class SmallLinearF32Function(torch.autograd.Function):
+    """y = x W^T + b for FEW rows in fp32 (outside autocast: MSDeformAttn's projections over the decoder's query rows): one launch
+    forward, one backward (csrc/small_linear_f32.hip) instead of addmm and mm + mm + sum."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        from .._lib import check, lib
+        k, co = x.shape[-1], w.shape[0]
+        x2 = x.reshape(-1, k)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        y = torch.empty((*x.shape[:-1], co), dtype=torch.float32, device=x.device)
+        check(lib().ocpg_small_linear_f32_fwd(x2.data_ptr(), w.data_ptr(), None if b is None else b.data_ptr(), x2.shape[0], k, co, y.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream), "ocpg_small_linear_f32_fwd")
+        ctx.save_for_backward(x2, w)
+        ctx.x_shape, ctx.has_bias = x.shape, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .._lib import check, lib
+        x2, w = ctx.saved_tensors
+        co, k = w.shape
+        g2 = gy.reshape(-1, co)
+        if g2.dtype != torch.float32:
+            g2 = g2.float()
+        if not g2.is_contiguous():
+            g2 = g2.contiguous()
+        gx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(w)
+        gb = torch.empty(co, dtype=torch.float32, device=w.device) if ctx.has_bias else None
+        check(lib().ocpg_small_linear_f32_bwd(g2.data_ptr(), x2.data_ptr(), w.data_ptr(), x2.shape[0], k, co, None if gx is None else gx.data_ptr(),
+                                              gw.data_ptr(), None if gb is None else gb.data_ptr(), torch.cuda.current_stream().cuda_stream),
+              "ocpg_small_linear_f32_bwd")
+        return (None if gx is None else gx.view(ctx.x_shape)), gw, gb
+
+
+def _small_linear_f32_ok(x, w, b):
+    k = x.shape[-1]
+    return (SMALL_LINEAR_F32 and x.is_cuda and torch.is_grad_enabled() and not torch.is_autocast_enabled("cuda") and w.dim() == 2 and k % 64 == 0
+            and k <= 512 and 0 < x.numel() <= 1024 * k and x.dtype == torch.float32 and w.dtype == torch.float32 and w.is_contiguous()
+            and w.requires_grad and (b is None or (b.dtype == torch.float32 and b.is_contiguous())))
+
+
 def _small_linear_ok(x, w, b):
     k = x.shape[-1]
     return (SMALL_LINEAR and x.is_cuda and torch.is_grad_enabled() and torch.is_autocast_enabled("cuda")
@@ -498,6 +543,8 @@ def linear(x, w, b):
     k = x.shape[-1]
     if _small_linear_ok(x, w, b):
         return SmallLinearFunction.apply(x, w, b)
+    if _small_linear_f32_ok(x, w, b):
+        return SmallLinearF32Function.apply(x, w, b)
     if SPLIT_K and x.is_cuda and w.requires_grad and x.numel() >= 8192 * k and torch.is_grad_enabled():
         if torch.is_autocast_enabled("cuda"):
             dt = torch.get_autocast_dtype("cuda")

@@ -24,6 +24,20 @@ class MultiheadAttention(nn.Module):
         nn.init.xavier_uniform_(self.in_proj_weight)
         nn.init.zeros_(self.out_proj.bias)
 
+    def forward_batch_first(self, query, key, value, key_padding_mask=None):
+        """query [B, Lq, C] (batch-first), key / value [Lk, B, C] -> [B, Lq, C], or None when the short-key HIP kernel does not serve the
+        call (the caller then takes forward() on the token-major layout).  Same arithmetic per token as forward()."""
+        B, Lq, C = query.shape
+        H, hd = self.num_heads, C // self.num_heads
+        if not (HIP_SMALLK and query.is_cuda and hd == 32 and key.shape[0] <= 32 and H <= 8 and not (self.training and self.dropout > 0)):
+            return None
+        w, b = lookup(self.in_proj_weight), lookup(self.in_proj_bias)
+        wq, wk, wv = w.chunk(3)
+        bq, bk, bv = b.chunk(3)
+        q, k, v = amp_cache.linear(query, wq, bq), amp_cache.linear(key, wk, bk), amp_cache.linear(value, wv, bv)
+        o = attn_smallk_func.attention_batch_first(q, k, v, key_padding_mask, hd ** -0.5, H)
+        return None if o is None else self.out_proj(o)
+
     def forward(self, query, key, value, key_padding_mask=None):
         """query [Lq,B,C], key/value [Lk,B,C], key_padding_mask [B,Lk] (True = ignore) -> [Lq,B,C]."""
         Lq, B, C = query.shape

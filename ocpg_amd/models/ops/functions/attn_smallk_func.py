@@ -72,3 +72,57 @@ def attention(q, k, v, key_padding_mask, scale, H, pdrop=0.0, rng=None):
     if not supported(q, k, H, pdrop):
         return None
     return SmallKeyAttention.apply(q, k, v, key_padding_mask, scale, H, pdrop, rng)
+
+
+class SmallKeyAttentionBF(Function):
+    """The same attention for queries stored BATCH-FIRST, q [B, Lq, C] (round 4: the visual tokens of the text gate are the channels-last
+    feature map itself, [b, (t h w), c]; putting them token-major and back cost two transposing copies of the map each way).  One launch
+    per batch entry on the [L, 1, C] view of its rows; k / v stay [Lk, B, C] (row stride B * C per entry, no copy).  No dropout."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, key_pad, scale, H):
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        B, Lq, C = q.shape
+        Lk = k.shape[0]
+        pad = None if key_pad is None else key_pad.to(torch.uint8).contiguous()
+        out = torch.empty((B, Lq, C), dtype=q.dtype, device=q.device)
+        lse = torch.empty((B, Lq, H), dtype=torch.float32, device=q.device)
+        es = q.element_size()
+        with torch.cuda.device(q.device):
+            for b in range(B):
+                rc = lib().ocpg_attn_smallk_fwd(q.data_ptr() + b * Lq * C * es, C, k.data_ptr() + b * C * es, B * C, v.data_ptr() + b * C * es, B * C,
+                                                None if pad is None else pad.data_ptr() + b * Lk, float(scale), Lq, 1, H, C // H, Lk, 0.0, 0, 0, None,
+                                                out.data_ptr() + b * Lq * C * es, C, lse.data_ptr() + b * Lq * H * 4, _DT[q.dtype], stream_ptr())
+                check(rc, "ocpg_attn_smallk_fwd")
+        ctx.save_for_backward(q, k, v, pad, lse)
+        ctx.meta = (float(scale), H)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        q, k, v, pad, lse = ctx.saved_tensors
+        scale, H = ctx.meta
+        B, Lq, C = q.shape
+        Lk = k.shape[0]
+        dout = dout.contiguous()
+        dq = torch.empty((B, Lq, C), dtype=q.dtype, device=q.device)
+        dkv = torch.zeros((2, B, Lk, C), dtype=torch.float32, device=q.device)
+        es = q.element_size()
+        with torch.cuda.device(q.device):
+            for b in range(B):
+                rc = lib().ocpg_attn_smallk_bwd(q.data_ptr() + b * Lq * C * es, C, k.data_ptr() + b * C * es, B * C, v.data_ptr() + b * C * es, B * C,
+                                                None if pad is None else pad.data_ptr() + b * Lk, dout.data_ptr() + b * Lq * C * es, C,
+                                                lse.data_ptr() + b * Lq * H * 4, scale, Lq, 1, H, C // H, Lk, 0.0, 0, 0, None,
+                                                dq.data_ptr() + b * Lq * C * es, C, dkv[0, b].data_ptr(), dkv[1, b].data_ptr(), _DT[q.dtype],
+                                                stream_ptr())
+                check(rc, "ocpg_attn_smallk_bwd")
+        dkv = dkv.transpose(1, 2).to(k.dtype)               # [2, Lk, B, C]
+        return dq, dkv[0], dkv[1], None, None, None
+
+
+def attention_batch_first(q, k, v, key_padding_mask, scale, H):
+    """q [B, Lq, C], k / v [Lk, B, C] -> [B, Lq, C]; None when csrc/attn_smallk.hip does not serve the shape."""
+    if not (q.is_cuda and q.dtype in _DT and q.shape[-1] % H == 0 and q.shape[-1] // H == 32 and H <= 8 and 256 % H == 0 and k.shape[0] <= 32):
+        return None
+    return SmallKeyAttentionBF.apply(q, k, v, key_padding_mask, scale, H)

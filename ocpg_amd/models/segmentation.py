@@ -27,6 +27,12 @@ class VisionLanguageFusionModule(nn.Module):
         k = text if text_pos is None else text + text_pos
         return visual * self.multihead_attn(q, k, text, key_padding_mask=text_key_padding_mask)
 
+    def forward_batch_first(self, visual, text, text_key_padding_mask=None, text_pos=None):
+        """visual [b, L, c] (the channels-last map's own memory) -> [b, L, c], or None when the attention kernel does not serve the call."""
+        k = text if text_pos is None else text + text_pos
+        a = self.multihead_attn.forward_batch_first(visual, k, text, key_padding_mask=text_key_padding_mask)
+        return None if a is None else visual * a
+
 
 def dice_loss(inputs, targets, num_boxes):
     p = inputs.sigmoid().flatten(1)
