@@ -317,7 +317,9 @@ def test_segmented_graph_step_matches_single_graph(dev):
                 lo, hi = b.data_ptr(), b.data_ptr() + 4 * b.numel()
                 covered += sum(p.grad.numel() for p in seg.params if lo <= p.grad.data_ptr() < hi)
         assert covered == sum(p.numel() for p in seg.params), (covered, sum(p.numel() for p in seg.params))
-        assert sum(len(bk["dense"]) for bk in seg.buckets) == 5           # one flat buffer per fused-cast group
+        # one flat buffer per fused-cast group (small 1-D bases may join them: the bias gradient of a folded projection, whose two
+        # parameters' gradients are slices of one vector, is reduced in place as well)
+        assert sum(1 for bk in seg.buckets for b in bk["dense"] if b.numel() >= 100000) == 5, [[b.numel() for b in bk["dense"]] for bk in seg.buckets]
     finally:
         torch.backends.cudnn.deterministic = det_before
         amp_cache.set_groups(model, None)
