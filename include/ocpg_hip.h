@@ -204,6 +204,10 @@ int ocpg_conv3x3_mfma_dgrad(const void* dy, const void* wT, int N, int H, int W,
  * [Cin] or NULL (= 1).  Saves one ocpg_bn_act_bwd pass per bottleneck. */
 int ocpg_conv3x3_mfma_dgrad_masked(const void* dy, const void* wT, const void* mask_y, const float* scale, int N, int H, int W, int Cin,
                                    int Cout, int stride, void* dx, void* stream);
+/* The same from the convolution's OWN weight w [Cout, 3, 3, Cin] (round 4: no transposed copy per step; the kernel reads its weight
+ * fragments with transposing LDS loads).  mask_y / scale as above (NULL: plain input gradient).  Cin % 8 != 0: -2000. */
+int ocpg_conv3x3_mfma_dgrad_w(const void* dy, const void* w, const void* mask_y, const float* scale, int N, int H, int W, int Cin, int Cout,
+                              int stride, void* dx, void* stream);
 
 /* Split-K form of ocpg_conv3x3_mfma_fwd for convolutions with FEW output pixels and a LONG reduction (round 4): the neck's extra level
  * input_proj[3] = nn.Conv2d(2048, 256, 3, stride=2, padding=1) (models/ocpg.py:119-123; 600 output pixels at config #2, K = 18 432) --

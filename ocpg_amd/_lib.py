@@ -36,6 +36,7 @@ SIGNATURES = {
     "ocpg_conv3x3_mfma_fwd_cols": [_vp, _vp, _vp, _vp] + [_int] * 7 + [_vp, _vp, _vp],
     "ocpg_conv3x3_mfma_dgrad": [_vp, _vp] + [_int] * 6 + [_vp, _vp],
     "ocpg_conv3x3_mfma_dgrad_masked": [_vp, _vp, _vp, _vp] + [_int] * 6 + [_vp, _vp],
+    "ocpg_conv3x3_mfma_dgrad_w": [_vp, _vp, _vp, _vp] + [_int] * 6 + [_vp, _vp],
     "ocpg_conv3x3_mfma_splits": [_int] * 6,
     "ocpg_conv3x3_mfma_fwd_splitk": [_vp, _vp, _vp] + [_int] * 7 + [_vp, _vp, _int, _vp, _vp],
     "ocpg_gemm": [_vp, _vp, _vp, _vp] + [_int] * 4 + [ctypes.c_longlong] * 10 + [ctypes.c_float, ctypes.c_float, _vp],

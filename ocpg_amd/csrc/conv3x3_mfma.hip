@@ -65,7 +65,12 @@ __device__ __forceinline__ bool tap_source(const ConvGeom& g, int y, int x, int 
 // partial sums part[z][row][col] (y = that buffer; no affine / ReLU: ocpg_splitk_reduce finishes) -- for convolutions whose GEMM has few
 // rows and a long K: the neck's stride-2 level (models/ocpg.py:119-123: 600 output pixels x 256 channels, K = 18 432 = 288 steps on 40
 // workgroups without the split).
-template <bool DGRAD, int BN, bool SPLITK = false>
+// BTR (input gradient only; round 4): the weight operand is the convolution's OWN weight [Cout_conv, 3, 3, Cin_conv] (no per-step
+// transposed copy: 30 ATen transposes, 0.26 ms per step).  For the input gradient the GEMM's K axis is (tap, output channel) and its N axis
+// the input channel, so a K step's B tile is 64 weight ROWS (k) x BN contiguous input channels (n): it is staged as it lies, [k][n], and
+// the MFMA fragments -- 8 consecutive k of one n -- are read TRANSPOSED with gfx950's ds_read_b64_tr_b16 (per 16-lane group a 4-row x
+// 16-column block, delivered column-major: lane 4q + p supplies row q, columns 4p..4p+3, lane i receives column i of the 4 rows).
+template <bool DGRAD, int BN, bool SPLITK = false, bool BTR = false>
 __global__ __launch_bounds__(NT) void conv3x3_mfma(const __hip_bfloat16* __restrict__ x, const __hip_bfloat16* __restrict__ w,
                                                    const float* __restrict__ scale, const float* __restrict__ bias, int relu, ConvGeom g,
                                                    __hip_bfloat16* __restrict__ y, __hip_bfloat16* __restrict__ cols,
@@ -73,6 +78,10 @@ __global__ __launch_bounds__(NT) void conv3x3_mfma(const __hip_bfloat16* __restr
   // mask (round 4; same [row][column] layout as y, or null): an element is kept only where mask > 0 -- the input-gradient launch then ALSO
   // does the frozen-BN + ReLU backward of the layer in front (gz = gx * scale[c] * [y_prev > 0], csrc/bn_act.hip's job until round 3)
   static_assert(!SPLITK || BN == 64, "the split-K epilogue is the 64-column one");
+  static_assert(!BTR || DGRAD, "the untransposed weight operand is the input gradient's");
+  constexpr int BROW = BN + 8;           // BTR: LDS row of the [k][n] B tile (bf16 elements; 16-byte aligned, rows 4 banks apart)
+  constexpr int BSEG = BN / 8;           // BTR: 16-byte segments per staged k row
+  static_assert(BK * BROW <= BN * LDS_ROW, "the [k][n] image fits the [n][k] one's buffer");
   constexpr int B_L = BN / ROWS_PER_PASS, NJ = BN / 64, WN = BN / 2;      // a wave's tile: 32 rows x WN columns = NJ MFMA tiles
   // 64-column tiles: the four waves split the K STEP instead of the tile (wave w takes the 16-wide slice w of every 64-wide step and
   // accumulates the whole 64 x 64 tile = 2 x 2 MFMA tiles): two A and two B fragments feed four MFMAs, where a 32 x 32 wave tile reads
@@ -111,7 +120,14 @@ __global__ __launch_bounds__(NT) void conv3x3_mfma(const __hip_bfloat16* __restr
   const long long wrow_stride = 9LL * C;                   // elements between consecutive GEMM-N rows of the weight operand
   const __hip_bfloat16* wp[B_L];                           // rows past Cout are clamped: their columns are never stored
 #pragma unroll
-  for (int i = 0; i < B_L; ++i) wp[i] = w + (long long)min(n0 + srow + i * ROWS_PER_PASS, g.Cout - 1) * wrow_stride + sseg * 8;
+  for (int i = 0; i < B_L; ++i) {
+    if constexpr (BTR) {                                     // segment e of the [64 k][BN n] tile: k row e / BSEG, columns 8 (e % BSEG)..
+      const int e = tid + i * NT, kr = e / BSEG, ns = e % BSEG;
+      wp[i] = w + (long long)kr * (9LL * g.Cout) + min(n0 + ns * 8, g.Cout - 8);      // (a weight row is 9 * Cin_conv long; Cin_conv = g.Cout here)
+    } else {
+      wp[i] = w + (long long)min(n0 + srow + i * ROWS_PER_PASS, g.Cout - 1) * wrow_stride + sseg * 8;
+    }
+  }
 
   // NSETS register sets: the loads of K step s + NSETS + 1 are issued while step s computes, so a load has NSETS MFMA phases
   // (not a fraction of one) to come back -- at ~1 workgroup per CU (300 workgroups for ResNet-101's layer3 shape) nothing
@@ -141,7 +157,7 @@ __global__ __launch_bounds__(NT) void conv3x3_mfma(const __hip_bfloat16* __restr
       if (!ok) { ys = 0; xs = 0; z |= 1u << i; }
       a[i] = *reinterpret_cast<const uint4*>(x + (((long long)pn[i] * g.Hs + ys) * g.Ws + xs) * C + c0);
     }
-    const long long woff = (long long)tap * C + fc * BK;
+    const long long woff = BTR ? (long long)fc * BK * (9LL * g.Cout) + (long long)tap * g.Cout : (long long)tap * C + fc * BK;
 #pragma unroll
     for (int i = 0; i < B_L; ++i) bq[i] = *reinterpret_cast<const uint4*>(wp[i] + woff);
     if (++f_tap == 9) { f_tap = 0; ++f_c; }
@@ -152,7 +168,14 @@ __global__ __launch_bounds__(NT) void conv3x3_mfma(const __hip_bfloat16* __restr
     for (int i = 0; i < A_L; ++i)
       *reinterpret_cast<uint4*>(&As[buf][(srow + i * ROWS_PER_PASS) * LDS_ROW + sseg * 8]) = ((z >> i) & 1u) ? make_uint4(0u, 0u, 0u, 0u) : a[i];
 #pragma unroll
-    for (int i = 0; i < B_L; ++i) *reinterpret_cast<uint4*>(&Bs[buf][(srow + i * ROWS_PER_PASS) * LDS_ROW + sseg * 8]) = bq[i];
+    for (int i = 0; i < B_L; ++i) {
+      if constexpr (BTR) {
+        const int e = tid + i * NT;
+        *reinterpret_cast<uint4*>(&Bs[buf][(e / BSEG) * BROW + (e % BSEG) * 8]) = bq[i];
+      } else {
+        *reinterpret_cast<uint4*>(&Bs[buf][(srow + i * ROWS_PER_PASS) * LDS_ROW + sseg * 8]) = bq[i];
+      }
+    }
     if constexpr (!DGRAD) {
       // the gathered A tiles ARE the rows of the patch (im2col) matrix the weight gradient contracts with: the column-0 workgroups
       // write them out on the way (16 bytes per thread and row) and the backward needs no im2col pass
@@ -172,14 +195,31 @@ __global__ __launch_bounds__(NT) void conv3x3_mfma(const __hip_bfloat16* __restr
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
   const int fr = lane & 31, fh = lane >> 5;                // fragment row / k-half of this lane
+  // BTR: fragment (8 consecutive k from k0 + 8 fh, column ncol0 + fr) out of the [k][n] tile by two transposing reads
+  auto btr = [&](int buf, int k0, int ncol0) -> bf16x8 {
+    typedef short s4 __attribute__((ext_vector_type(4)));
+    const int li = lane & 15, grp = lane >> 4;
+    const short* p = &Bs[buf][(k0 + 8 * fh + (li >> 2)) * BROW + ncol0 + 16 * (grp & 1) + 4 * (li & 3)];
+    const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)p);
+    const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(p + 4 * BROW));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+  };
   auto compute = [&](int buf) {
     if constexpr (KSPLIT) {
       static_assert(BK / 16 == NT / 64, "one 16-wide K slice per wave");
       const int ko = wave * 16 + fh * 8;
       const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&As[buf][fr * LDS_ROW + ko]);
       const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&As[buf][(32 + fr) * LDS_ROW + ko]);
-      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(&Bs[buf][fr * LDS_ROW + ko]);
-      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(&Bs[buf][(32 + fr) * LDS_ROW + ko]);
+      bf16x8 b0, b1;
+      if constexpr (BTR) {
+        b0 = btr(buf, wave * 16, 0);
+        b1 = btr(buf, wave * 16, 32);
+      } else {
+        b0 = *reinterpret_cast<const bf16x8*>(&Bs[buf][fr * LDS_ROW + ko]);
+        b1 = *reinterpret_cast<const bf16x8*>(&Bs[buf][(32 + fr) * LDS_ROW + ko]);
+      }
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[1], 0, 0, 0);
       acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[2], 0, 0, 0);
@@ -191,7 +231,9 @@ __global__ __launch_bounds__(NT) void conv3x3_mfma(const __hip_bfloat16* __restr
       const bf16x8 a = *reinterpret_cast<const bf16x8*>(&As[buf][(wm * 32 + fr) * LDS_ROW + kk * 16 + fh * 8]);
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(&Bs[buf][(wn * WN + j * 32 + fr) * LDS_ROW + kk * 16 + fh * 8]);
+        bf16x8 b;
+        if constexpr (BTR) b = btr(buf, kk * 16, wn * WN + j * 32);
+        else b = *reinterpret_cast<const bf16x8*>(&Bs[buf][(wn * WN + j * 32 + fr) * LDS_ROW + kk * 16 + fh * 8]);
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
       }
     }
@@ -417,6 +459,29 @@ extern "C" int ocpg_conv3x3_mfma_dgrad_masked(const void* dy, const void* wT, co
   else
     conv3x3_mfma<true, 128><<<dim3(mt, (unsigned)((Cin + 127) / 128)), NT, 0, (hipStream_t)stream>>>(
         (const __hip_bfloat16*)dy, (const __hip_bfloat16*)wT, scale, nullptr, 0, g, (__hip_bfloat16*)dx, nullptr, (const __hip_bfloat16*)mask_y);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// The same from the convolution's OWN weight w [Cout, 3, 3, Cin] (no transposed copy; Cin % 8 == 0).
+extern "C" int ocpg_conv3x3_mfma_dgrad_w(const void* dy, const void* w, const void* mask_y, const float* scale, int N, int H, int W, int Cin, int Cout,
+                                         int stride, void* dx, void* stream) {
+  if (N < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return -1006;
+  if ((stride != 1 && stride != 2) || Cout % BK != 0 || Cin % 8 != 0) return -2000;
+  if (N == 0) return 0;
+  if (!dy) return -1001;
+  if (!w) return -1002;
+  if (!dx) return -1011;
+  ConvGeom g;
+  g.N = N; g.H = H; g.W = W; g.C = Cout; g.Hs = (H - 1) / stride + 1; g.Ws = (W - 1) / stride + 1; g.Cout = Cin; g.stride = stride;
+  g.M = (long long)N * H * W;
+  const unsigned mt = (unsigned)((g.M + BM - 1) / BM);
+  if (narrow_tiles(mt, Cin))
+    conv3x3_mfma<true, 64, false, true><<<dim3(mt, (unsigned)((Cin + 63) / 64)), NT, 0, (hipStream_t)stream>>>(
+        (const __hip_bfloat16*)dy, (const __hip_bfloat16*)w, scale, nullptr, 0, g, (__hip_bfloat16*)dx, nullptr, (const __hip_bfloat16*)mask_y);
+  else
+    conv3x3_mfma<true, 128, false, true><<<dim3(mt, (unsigned)((Cin + 127) / 128)), NT, 0, (hipStream_t)stream>>>(
+        (const __hip_bfloat16*)dy, (const __hip_bfloat16*)w, scale, nullptr, 0, g, (__hip_bfloat16*)dx, nullptr, (const __hip_bfloat16*)mask_y);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }

@@ -300,6 +300,7 @@ def eligible3x3_mfma(x, conv):
             and x.shape[1] % 64 == 0 and conv.out_channels % 64 == 0 and x.shape[1] >= _MFMA_MIN_C and conv.out_channels >= _MFMA_MIN_C)
 
 
+DGRAD_OWN_WEIGHT = os.environ.get("OCPG_DGRAD_OWN_WEIGHT", "1") != "0"     # A/B switch: conv3x3_mfma's input gradient reads the weight untransposed
 _MFMA_MIN_C = int(os.environ.get("OCPG_MFMA_CONV3X3_MIN_C", "128"))     # 64 also serves layer1 (frozen: forward only), measured 0.08 ms/step SLOWER than MIOpen there (r4)
 
 
@@ -351,15 +352,18 @@ class Conv3x3MfmaBNAct(Function):
         check(L.ocpg_bn_act_bwd(gy.data_ptr(), y.data_ptr(), scale.data_ptr(), gz.data_ptr(), None, m, co, 1, int(relu), 1, st), "ocpg_bn_act_bwd")
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            wt = w2.permute(3, 1, 2, 0).contiguous()               # [c,3,3,co]
             gx = torch.empty((n, c, h, wd), dtype=y.dtype, device=y.device, memory_format=_CL)
-            tok = ctx.premask
-            if tok is not None:     # x IS the layer in front's bn + ReLU output: its backward rides in this kernel's epilogue
-                check(L.ocpg_conv3x3_mfma_dgrad_masked(gz.data_ptr(), wt.data_ptr(), x.data_ptr(), tok["scale"].data_ptr(), n, h, wd, c, co, stride,
-                                                       gx.data_ptr(), st), "ocpg_conv3x3_mfma_dgrad_masked")
-                tok["gz"] = gx
+            tok = ctx.premask       # x IS the layer in front's bn + ReLU output: its backward rides in this kernel's epilogue
+            mask_ptr, scale_ptr = (x.data_ptr(), tok["scale"].data_ptr()) if tok is not None else (None, None)
+            if DGRAD_OWN_WEIGHT and c % 8 == 0:      # the weight as it lies ([co,3,3,c]): transposing LDS reads, no per-step transposed copy
+                check(L.ocpg_conv3x3_mfma_dgrad_w(gz.data_ptr(), w2.data_ptr(), mask_ptr, scale_ptr, n, h, wd, c, co, stride, gx.data_ptr(), st),
+                      "ocpg_conv3x3_mfma_dgrad_w")
             else:
-                check(L.ocpg_conv3x3_mfma_dgrad(gz.data_ptr(), wt.data_ptr(), n, h, wd, c, co, stride, gx.data_ptr(), st), "ocpg_conv3x3_mfma_dgrad")
+                wt = w2.permute(3, 1, 2, 0).contiguous()               # [c,3,3,co]
+                check(L.ocpg_conv3x3_mfma_dgrad_masked(gz.data_ptr(), wt.data_ptr(), mask_ptr, scale_ptr, n, h, wd, c, co, stride, gx.data_ptr(), st),
+                      "ocpg_conv3x3_mfma_dgrad_masked")
+            if tok is not None:
+                tok["gz"] = gx
         if ctx.needs_input_grad[1]:
             from ...amp_cache import side_wgrad
             with side_wgrad(ctx.w_cast, gz, x) as sw:          # off the critical path: the weight-gradient stream (amp_cache.side_wgrad)

@@ -802,7 +802,8 @@ def test_bottleneck_premasked_input_gradient(dev, cin, width, stride, project):
             res.append([y.detach().float(), xi.grad.float()] + [p.grad.float() for p in blk.parameters()])
         finally:
             conv_bn_func.PREMASK = old
-    assert counts[0].get("ocpg_conv3x3_mfma_dgrad_masked", 0) == 1 and counts[1].get("ocpg_conv3x3_mfma_dgrad_masked", 0) == 0, counts
+    dgrad = lambda c: c.get("ocpg_conv3x3_mfma_dgrad_w", 0) + c.get("ocpg_conv3x3_mfma_dgrad_masked", 0)      # noqa: E731  (own / transposed weight)
+    assert dgrad(counts[0]) == 1 and dgrad(counts[1]) == 1, counts
     assert counts[0].get("ocpg_bn_act_bwd", 0) == counts[1].get("ocpg_bn_act_bwd", 0) - 1, counts
     assert torch.equal(res[0][0], res[1][0])
     for a, b_ in zip(res[0][1:], res[1][1:]):
@@ -1176,12 +1177,16 @@ def test_small_key_attention_dropout(dev):
 @pytest.mark.parametrize("n,c,co,h,w,stride", [(10, 256, 256, 24, 40, 1), (2, 128, 128, 48, 80, 1), (3, 256, 256, 48, 80, 2),
                                                 (2, 512, 512, 12, 20, 1), (1, 128, 256, 7, 9, 2), (2, 192, 320, 5, 6, 1)])
 @pytest.mark.parametrize("relu", [True, False])
-def test_conv3x3_mfma_kernel(dev, n, c, co, h, w, stride, relu):
+@pytest.mark.parametrize("own_weight", [True, False])
+def test_conv3x3_mfma_kernel(dev, n, c, co, h, w, stride, relu, own_weight, monkeypatch):
     """csrc/conv3x3_mfma.hip (implicit-GEMM bf16 MFMA 3x3 conv + frozen-BN affine + ReLU in the epilogue, its input-gradient
     twin, im2col + GEMM weight gradient) against F.conv2d in fp32 on the same bf16-rounded operands followed by the affine:
     ResNet-101 layer2/3/4 shapes incl. the stride-2 blocks, a ragged map (tiles with masked rows) and channel counts that are
     not multiples of the 128-wide output tile."""
     from ocpg_amd.models.ops.functions import conv_bn_func as f
+    # own_weight (round 4): the input gradient reads the weight as it lies, through transposing LDS loads (ocpg_conv3x3_mfma_dgrad_w);
+    # False: from a transposed copy (ocpg_conv3x3_mfma_dgrad_masked)
+    monkeypatch.setattr(f, "DGRAD_OWN_WEIGHT", own_weight)
     g = torch.Generator(device="cpu").manual_seed(n * 1000 + c + h)
     x = torch.randn(n, c, h, w, generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     wt = (torch.randn(co, c, 3, 3, generator=g) * (2.0 / (9 * c)) ** 0.5).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
