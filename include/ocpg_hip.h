@@ -208,6 +208,12 @@ int ocpg_conv3x3_mfma_dgrad_masked(const void* dy, const void* wT, const void* m
  * fragments with transposing LDS loads).  mask_y / scale as above (NULL: plain input gradient).  Cin % 8 != 0: -2000. */
 int ocpg_conv3x3_mfma_dgrad_w(const void* dy, const void* w, const void* mask_y, const float* scale, int N, int H, int W, int Cin, int Cout,
                               int stride, void* dx, void* stream);
+/* Weight gradient of the same convolution straight from the two channels-last maps (csrc/conv3x3_wgrad.hip; round 4: replaces
+ * ocpg_im2col3x3_nhwc + a row-split ocpg_gemm): gz [N,Ho,Wo,Cout] bf16 (the gradient after the BN / ReLU backward), x [N,H,W,Cin] bf16 ->
+ * part [S][Cout][3][3][Cin] bf16, S = ocpg_conv3x3_mfma_wgrad_splits(...) partial sums over ranges of output rows (the caller adds them:
+ * gw = sum_z part[z]).  Cin % 8 or Cout % 8 != 0: -2000. */
+int ocpg_conv3x3_mfma_wgrad_splits(int N, int H, int W, int Cin, int Cout, int stride);
+int ocpg_conv3x3_mfma_wgrad(const void* gz, const void* x, int N, int H, int W, int Cin, int Cout, int stride, void* part, void* stream);
 
 /* Split-K form of ocpg_conv3x3_mfma_fwd for convolutions with FEW output pixels and a LONG reduction (round 4): the neck's extra level
  * input_proj[3] = nn.Conv2d(2048, 256, 3, stride=2, padding=1) (models/ocpg.py:119-123; 600 output pixels at config #2, K = 18 432) --

@@ -300,6 +300,7 @@ def eligible3x3_mfma(x, conv):
             and x.shape[1] % 64 == 0 and conv.out_channels % 64 == 0 and x.shape[1] >= _MFMA_MIN_C and conv.out_channels >= _MFMA_MIN_C)
 
 
+WGRAD_OWN = os.environ.get("OCPG_WGRAD_OWN", "1") != "0"     # A/B switch: conv3x3_mfma's weight gradient by csrc/conv3x3_wgrad.hip (0 = im2col + row-split GEMM)
 DGRAD_OWN_WEIGHT = os.environ.get("OCPG_DGRAD_OWN_WEIGHT", "1") != "0"     # A/B switch: conv3x3_mfma's input gradient reads the weight untransposed
 _MFMA_MIN_C = int(os.environ.get("OCPG_MFMA_CONV3X3_MIN_C", "128"))     # 64 also serves layer1 (frozen: forward only), measured 0.08 ms/step SLOWER than MIOpen there (r4)
 
@@ -368,21 +369,28 @@ class Conv3x3MfmaBNAct(Function):
             from ...amp_cache import side_wgrad
             with side_wgrad(ctx.w_cast, gz, x) as sw:          # off the critical path: the weight-gradient stream (amp_cache.side_wgrad)
                 st = torch.cuda.current_stream().cuda_stream
-                if ctx.has_cols:
-                    cols = ctx.saved_tensors[4]
+                if WGRAD_OWN and not ctx.has_cols and c % 8 == 0 and co % 8 == 0:
+                    # straight from the two maps (csrc/conv3x3_wgrad.hip): no patch matrix, no library GEMM
+                    sp = int(L.ocpg_conv3x3_mfma_wgrad_splits(n, h, wd, c, co, stride))
+                    part = torch.empty((sp, co, k), dtype=y.dtype, device=y.device)
+                    check(L.ocpg_conv3x3_mfma_wgrad(gz.data_ptr(), x.data_ptr(), n, h, wd, c, co, stride, part.data_ptr(), st), "ocpg_conv3x3_mfma_wgrad")
+                    g2 = _reduce_partials(part, ctx.w_cast) if sp > 1 else part[0]
                 else:
-                    cols = torch.empty((m, k), dtype=y.dtype, device=y.device)
-                    check(L.ocpg_im2col3x3_nhwc(x.data_ptr(), n, h, wd, c, stride, 1, cols.data_ptr(), 1, st), "ocpg_im2col3x3_nhwc")
-                if splits > 1 and m % splits == 0:
-                    r = m // splits
-                    part = torch.empty((splits, co, k), dtype=y.dtype, device=y.device)
-                    check(L.ocpg_gemm(gz.data_ptr(), cols.data_ptr(), part.data_ptr(), None, 1, 1, 1, 0, co, k, r, co, k, k, splits, r * co, r * k,
-                                      co * k, 1.0, 0.0, st), "ocpg_gemm")
-                    g2 = _reduce_partials(part, ctx.w_cast)
-                else:
-                    g2 = torch.empty((co, k), dtype=y.dtype, device=y.device)
-                    check(L.ocpg_gemm(gz.data_ptr(), cols.data_ptr(), g2.data_ptr(), None, 1, 1, 1, 0, co, k, m, co, k, k, 1, 0, 0, 0, 1.0, 0.0, st),
-                          "ocpg_gemm")
+                    if ctx.has_cols:
+                        cols = ctx.saved_tensors[4]
+                    else:
+                        cols = torch.empty((m, k), dtype=y.dtype, device=y.device)
+                        check(L.ocpg_im2col3x3_nhwc(x.data_ptr(), n, h, wd, c, stride, 1, cols.data_ptr(), 1, st), "ocpg_im2col3x3_nhwc")
+                    if splits > 1 and m % splits == 0:
+                        r = m // splits
+                        part = torch.empty((splits, co, k), dtype=y.dtype, device=y.device)
+                        check(L.ocpg_gemm(gz.data_ptr(), cols.data_ptr(), part.data_ptr(), None, 1, 1, 1, 0, co, k, r, co, k, k, splits, r * co, r * k,
+                                          co * k, 1.0, 0.0, st), "ocpg_gemm")
+                        g2 = _reduce_partials(part, ctx.w_cast)
+                    else:
+                        g2 = torch.empty((co, k), dtype=y.dtype, device=y.device)
+                        check(L.ocpg_gemm(gz.data_ptr(), cols.data_ptr(), g2.data_ptr(), None, 1, 1, 1, 0, co, k, m, co, k, k, 1, 0, 0, 0, 1.0, 0.0, st),
+                              "ocpg_gemm")
                 gw = sw.publish(g2).view(co, 3, 3, c).permute(0, 3, 1, 2)          # channels-last strides of [co, c, 3, 3]
         return gx, gw, None, None, None, None, None
 

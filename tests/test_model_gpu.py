@@ -1179,6 +1179,16 @@ def test_small_key_attention_dropout(dev):
 @pytest.mark.parametrize("relu", [True, False])
 @pytest.mark.parametrize("own_weight", [True, False])
 def test_conv3x3_mfma_kernel(dev, n, c, co, h, w, stride, relu, own_weight, monkeypatch):
+    _conv3x3_mfma_case(dev, n, c, co, h, w, stride, relu, own_weight, own_weight, monkeypatch)
+
+
+@pytest.mark.parametrize("n,c,co,h,w,stride", [(2, 128, 128, 9, 70, 1), (1, 256, 128, 11, 67, 2), (3, 64, 192, 4, 3, 1), (1, 128, 64, 1, 1, 1)])
+def test_conv3x3_own_weight_gradient_segments_and_ragged_maps(dev, n, c, co, h, w, stride, monkeypatch):
+    """csrc/conv3x3_wgrad.hip on maps wider than one 64- / 32-pixel segment, odd sizes under stride 2, maps smaller than the kernel."""
+    _conv3x3_mfma_case(dev, n, c, co, h, w, stride, True, True, True, monkeypatch)
+
+
+def _conv3x3_mfma_case(dev, n, c, co, h, w, stride, relu, own_weight, own_wgrad, monkeypatch):
     """csrc/conv3x3_mfma.hip (implicit-GEMM bf16 MFMA 3x3 conv + frozen-BN affine + ReLU in the epilogue, its input-gradient
     twin, im2col + GEMM weight gradient) against F.conv2d in fp32 on the same bf16-rounded operands followed by the affine:
     ResNet-101 layer2/3/4 shapes incl. the stride-2 blocks, a ragged map (tiles with masked rows) and channel counts that are
@@ -1186,7 +1196,9 @@ def test_conv3x3_mfma_kernel(dev, n, c, co, h, w, stride, relu, own_weight, monk
     from ocpg_amd.models.ops.functions import conv_bn_func as f
     # own_weight (round 4): the input gradient reads the weight as it lies, through transposing LDS loads (ocpg_conv3x3_mfma_dgrad_w);
     # False: from a transposed copy (ocpg_conv3x3_mfma_dgrad_masked)
+    # own_wgrad (round 4): the weight gradient straight from the two maps (csrc/conv3x3_wgrad.hip); False: im2col + GEMM
     monkeypatch.setattr(f, "DGRAD_OWN_WEIGHT", own_weight)
+    monkeypatch.setattr(f, "WGRAD_OWN", own_wgrad)
     g = torch.Generator(device="cpu").manual_seed(n * 1000 + c + h)
     x = torch.randn(n, c, h, w, generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     wt = (torch.randn(co, c, 3, 3, generator=g) * (2.0 / (9 * c)) ** 0.5).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
