@@ -47,7 +47,8 @@ struct KeyHash {
     return (size_t)h;
   }
 };
-constexpr int kCandidates = 12;
+constexpr int kRanked = 12;               // candidates taken from the heuristic's ranked list
+constexpr int kCandidates = 160;          // ... + (OCPG_GEMM_TUNE_ALL=1) every other kernel of the library that supports the problem
 struct Plan {
   hipblasLtMatmulDesc_t desc = nullptr;
   hipblasLtMatrixLayout_t a = nullptr, b = nullptr, c = nullptr;
@@ -120,6 +121,11 @@ bool tuning_fp32() {      // experiment switch (default off): also time fp32 pla
 }
 
 int g_tuning_override = -1;       // ocpg_gemm_set_tuning: -1 = the environment decides
+bool tune_all() {
+  static const bool on = [] { const char* e = getenv("OCPG_GEMM_TUNE_ALL"); return !(e && e[0] == '0'); }();      // default on (round 4): -1.0 ms per step
+  return on;
+}
+
 bool tuning() {
   static const bool on = [] {
     const char* e = getenv("OCPG_GEMM_TUNE");
@@ -191,7 +197,7 @@ Plan build(State& s, const Key& key) {
   // the default: the heuristic's single best (exactly what at::mm would be given); it is also the reference the other candidates
   // are validated against.  fp32 plans keep it: the ranked list for fp32 holds kernels that are 2e-3 off (seen on a
   // [8200 x 1032] x [1032 x 64] product), and the MSDeformAttn projections are fp32 on purpose (deformable_transformer.py:250).
-  hipblasLtMatmulHeuristicResult_t res[kCandidates];
+  hipblasLtMatmulHeuristicResult_t res[kRanked];
   int found = 0;
   hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(s.handle, p.desc, p.a, p.b, p.c, p.c, pref, 1, res, &found);
   if (st != HIPBLAS_STATUS_SUCCESS || found < 1) { hipblasLtMatmulPreferenceDestroy(pref); p.status = -1105; return p; }
@@ -210,7 +216,7 @@ Plan build(State& s, const Key& key) {
   const bool default_unsafe = key.k < 256 && custom(p.algo);
   if ((tuning() && (key.dtype != 0 || tuning_fp32())) || default_unsafe) {
     found = 0;
-    st = hipblasLtMatmulAlgoGetHeuristic(s.handle, p.desc, p.a, p.b, p.c, p.c, pref, kCandidates - 1, res, &found);
+    st = hipblasLtMatmulAlgoGetHeuristic(s.handle, p.desc, p.a, p.b, p.c, p.c, pref, kRanked - 1, res, &found);
     if (default_unsafe) p.ncand = 0;            // the first safe kernel of the ranked list becomes the default
     for (int i = 0; st == HIPBLAS_STATUS_SUCCESS && i < found && p.ncand < kCandidates; ++i) {
       if (res[i].state != HIPBLAS_STATUS_SUCCESS || res[i].workspaceSize > kWorkspaceBytes || unsafe(res[i].algo)) continue;
@@ -218,6 +224,27 @@ Plan build(State& s, const Key& key) {
       if (default_unsafe && !(tuning() && (key.dtype != 0 || tuning_fp32())) && p.ncand == 1) break;
       p.cand[p.ncand] = res[i].algo;
       p.cand_ws[p.ncand++] = res[i].workspaceSize;
+    }
+  }
+  // OCPG_GEMM_TUNE_ALL (default 1, round 4): the heuristic ranks by a model; time EVERY Tensile kernel that supports the problem
+  // (hipblaslt_ext::getAllAlgos + matmulIsAlgoSupported, same validation against the default as the ranked ones).  The list order is
+  // the library's own, so the candidate indices stay comparable between ranks (gemm_sync).
+  if (tune_all() && tuning() && key.dtype != 0 && p.ncand >= 1) {
+    std::vector<hipblasLtMatmulHeuristicResult_t> all;
+    if (hipblaslt_ext::getAllAlgos(s.handle, hipblaslt_ext::GemmType::HIPBLASLT_GEMM, opa, opb, in, in, out, out, HIPBLAS_COMPUTE_32F, all) ==
+        HIPBLAS_STATUS_SUCCESS) {
+      const float one = 1.f, zero = 0.f;
+      for (size_t i = 0; i < all.size() && p.ncand < kCandidates; ++i) {
+        size_t need = 0;
+        if (hipblaslt_ext::matmulIsAlgoSupported(s.handle, p.desc, &one, p.a, p.b, &zero, p.c, p.c, all[i].algo, need) != HIPBLAS_STATUS_SUCCESS) continue;
+        if (need > kWorkspaceBytes || unsafe(all[i].algo)) continue;
+        const int idx = hipblaslt_ext::getIndexFromAlgo(all[i].algo);
+        bool dup = false;
+        for (int j = 0; j < p.ncand && !dup; ++j) dup = hipblaslt_ext::getIndexFromAlgo(p.cand[j]) == idx;
+        if (dup) continue;
+        p.cand[p.ncand] = all[i].algo;
+        p.cand_ws[p.ncand++] = need;
+      }
     }
   }
   hipblasLtMatmulPreferenceDestroy(pref);
