@@ -807,7 +807,9 @@ def main():
     amp_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}[a.dtype]
     make_samples, text, targets = synthetic_batch(a.clips_per_gpu, device, seed=42 + rank, roberta=a.text == "roberta")
     step, mode = None, "eager"
-    gemm_routing = "hipBLASLt plan cache (ocpg_gemm: candidates timed at first use) for every GEMM-shaped layer"
+    gemm_routing = ("hipBLASLt plan cache (ocpg_gemm: " + ("the heuristic's ranked dozen" if os.environ.get("OCPG_GEMM_TUNE_ALL") == "0"
+                                                           else "every Tensile kernel that supports the problem") +
+                    " timed and validated at first use) for every GEMM-shaped layer")
     eager_routing = "at::mm outside the ResNet body (the eager step is host-bound: DESIGN.md section 5)"
     fallback_note = None
     if a.eager and "OCPG_PLANNED_GEMM" not in os.environ:

@@ -4,4 +4,4 @@ cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r4
 OCPG_REHEARSE_ONE_GPU=1 timeout -k 10 500 python3 bench.py --gpus 2 --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-b1 > gpurun_out/r4/rehearse2.json 2> gpurun_out/r4/rehearse2.err; echo "rc=$?"
 tail -3 gpurun_out/r4/rehearse2.err
 python3 -c "
-import json; l=json.load(open('gpurun_out/r4/rehearse2.json')); print({k: l.get(k) for k in ('n_gpus','ms_per_step','ranks','hipgraph')}); print(l['config'])"
+import json; l=json.loads([x for x in open('gpurun_out/r4/rehearse2.json').read().splitlines() if x.startswith('{')][-1]); print({k: l.get(k) for k in ('n_gpus','ms_per_step','ranks','hipgraph')}); print(l['config'])"
