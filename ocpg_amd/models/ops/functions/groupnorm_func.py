@@ -68,9 +68,12 @@ def eligible(x, module):
 class GroupNorm(torch.nn.GroupNorm):
     """nn.GroupNorm (same parameters / state_dict).  For a channels-last GPU map with groups of 8 channels (the reference's
     GroupNorm(32, 256) on a projection output) the HIP pass; any other input takes ATen's group_norm.  The output is fp32
-    planes either way (autocast runs group_norm in fp32)."""
+    either way (autocast runs group_norm in fp32): channels-last when the LFM block behind it transforms this map size with its own
+    passes (csrc/lfm_dft.hip reads channels-last), planes when it keeps rocFFT (lengths with a prime factor > 16, e.g. config #5's
+    107-wide level: a channels-last map would cost that path two transposing copies)."""
 
     def forward(self, x):
         if eligible(x, self):
-            return GroupNormCLFunction.apply(x, self.weight, self.bias, self.num_groups, self.eps, CL_OUT)
+            cl = CL_OUT and bool(lib().ocpg_lfm_dft_supported(int(x.shape[2]), int(x.shape[3])))
+            return GroupNormCLFunction.apply(x, self.weight, self.bias, self.num_groups, self.eps, cl)
         return super().forward(x)
