@@ -13,6 +13,7 @@
 //  * bias+ReLU+dropout: backward needs only the OUTPUT (h > 0 <=> active and kept), which the next GEMM keeps anyway.
 // HBM-bound streaming kernels: 16 bytes per lane per access.
 #include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -49,6 +50,22 @@ template <> struct IO<__hip_bfloat16> {
       w[i] = (uint32_t)(*reinterpret_cast<const uint16_t*>(&lo)) | ((uint32_t)(*reinterpret_cast<const uint16_t*>(&hi)) << 16);
     }
     *reinterpret_cast<uint2*>(p) = make_uint2(w[0], w[1]);
+  }
+};
+
+template <> struct IO<__half> {          // fp16 storage (round 4: the reference's --amp dtype, BASELINE config #5)
+  static __device__ __forceinline__ void load4(const __half* p, float (&f)[4]) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    const __half2 a = *reinterpret_cast<const __half2*>(&v.x), b = *reinterpret_cast<const __half2*>(&v.y);
+    const float2 fa = __half22float2(a), fb = __half22float2(b);
+    f[0] = fa.x; f[1] = fa.y; f[2] = fb.x; f[3] = fb.y;
+  }
+  static __device__ __forceinline__ void store4(__half* p, const float (&f)[4]) {
+    const __half2 a = __floats2half2_rn(f[0], f[1]), b = __floats2half2_rn(f[2], f[3]);
+    uint2 v;
+    v.x = *reinterpret_cast<const uint32_t*>(&a);
+    v.y = *reinterpret_cast<const uint32_t*>(&b);
+    *reinterpret_cast<uint2*>(p) = v;
   }
 };
 
@@ -292,11 +309,11 @@ int ocpg_dropout_add_ln_fwd(const void* x, const float* res, const float* gamma,
   const float scale = 1.f / (1.f - p);
   const unsigned grid = (unsigned)((R + 3) / 4);
   hipStream_t st = (hipStream_t)stream;
-  if (x_dtype != 0 && x_dtype != 1) return -1008;
+  if (x_dtype < 0 || x_dtype > 2) return -1008;
   const int nc = (C + 255) / 256;
 #define DAL_FWD(XT_, N_) dal_fwd<XT_, N_><<<grid, 256, 0, st>>>((const XT_*)x, res, gamma, beta, R, C, eps, thr, scale, seed, offset, (const uint64_t*)rng_base, y, mean, rstd)
 #define DAL_FWD_T(XT_) do { if (nc <= 1) DAL_FWD(XT_, 1); else if (nc <= 2) DAL_FWD(XT_, 2); else if (nc <= 4) DAL_FWD(XT_, 4); else DAL_FWD(XT_, 8); } while (0)
-  if (x_dtype == 0) DAL_FWD_T(float); else DAL_FWD_T(__hip_bfloat16);
+  if (x_dtype == 0) DAL_FWD_T(float); else if (x_dtype == 1) DAL_FWD_T(__hip_bfloat16); else DAL_FWD_T(__half);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
@@ -318,11 +335,11 @@ int ocpg_dropout_add_ln_bwd(const float* gy, const void* x, const float* res, co
   const float scale = 1.f / (1.f - p);
   const unsigned grid = (unsigned)ocpg_dropout_add_ln_bwd_slots(R);
   hipStream_t st = (hipStream_t)stream;
-  if (x_dtype != 0 && x_dtype != 1) return -1008;
+  if (x_dtype < 0 || x_dtype > 2) return -1008;
   const int nc = (C + 255) / 256;
 #define DAL_BWD(XT_, N_) dal_bwd<XT_, N_><<<grid, 256, 0, st>>>(gy, (const XT_*)x, res, gamma, mean, rstd, R, C, thr, scale, seed, offset, (const uint64_t*)rng_base, (XT_*)gx, gres, dgb_part)
 #define DAL_BWD_T(XT_) do { if (nc <= 1) DAL_BWD(XT_, 1); else if (nc <= 2) DAL_BWD(XT_, 2); else if (nc <= 4) DAL_BWD(XT_, 4); else DAL_BWD(XT_, 8); } while (0)
-  if (x_dtype == 0) DAL_BWD_T(float); else DAL_BWD_T(__hip_bfloat16);
+  if (x_dtype == 0) DAL_BWD_T(float); else if (x_dtype == 1) DAL_BWD_T(__hip_bfloat16); else DAL_BWD_T(__half);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
@@ -336,7 +353,7 @@ int ocpg_bias_relu_dropout_fwd(const void* a, const void* bias, long long R, int
   if (!h) return -1010;
   const uint32_t thr = threshold(p);
   const float scale = 1.f / (1.f - p);
-  const int V = (dtype == 1 && C % 8 == 0) ? 2 : 1;
+  const int V = (dtype != 0 && C % 8 == 0) ? 2 : 1;
   const long long totalv = R * C / (4 * V);
   const long long want = (totalv + 255) / 256;
   const unsigned grid = (unsigned)(want < 256 * 32 ? want : 256 * 32);
@@ -344,13 +361,15 @@ int ocpg_bias_relu_dropout_fwd(const void* a, const void* bias, long long R, int
   if (dtype == 0) brd_fwd<float, 1><<<grid, 256, 0, st>>>((const float*)a, (const float*)bias, totalv, C, thr, scale, seed, offset, (const uint64_t*)rng_base, (float*)h);
   else if (dtype == 1 && V == 2) brd_fwd<__hip_bfloat16, 2><<<grid, 256, 0, st>>>((const __hip_bfloat16*)a, (const __hip_bfloat16*)bias, totalv, C, thr, scale, seed, offset, (const uint64_t*)rng_base, (__hip_bfloat16*)h);
   else if (dtype == 1) brd_fwd<__hip_bfloat16, 1><<<grid, 256, 0, st>>>((const __hip_bfloat16*)a, (const __hip_bfloat16*)bias, totalv, C, thr, scale, seed, offset, (const uint64_t*)rng_base, (__hip_bfloat16*)h);
+  else if (dtype == 2 && V == 2) brd_fwd<__half, 2><<<grid, 256, 0, st>>>((const __half*)a, (const __half*)bias, totalv, C, thr, scale, seed, offset, (const uint64_t*)rng_base, (__half*)h);
+  else if (dtype == 2) brd_fwd<__half, 1><<<grid, 256, 0, st>>>((const __half*)a, (const __half*)bias, totalv, C, thr, scale, seed, offset, (const uint64_t*)rng_base, (__half*)h);
   else return -1008;
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
 
 static int brd_rows_per_sweep(int C, int dtype) {
-  const int V = (dtype == 1 && C % 8 == 0) ? 2 : 1;
+  const int V = (dtype != 0 && C % 8 == 0) ? 2 : 1;
   const int lpr = C / (4 * V);
   return lpr >= 256 ? 1 : 256 / lpr;
 }
@@ -372,11 +391,13 @@ int ocpg_bias_relu_dropout_bwd(const void* gh, const void* h, long long R, int C
   if (!ga || !dbias) return -1010;
   const float scale = 1.f / (1.f - p);
   hipStream_t st = (hipStream_t)stream;
-  const int V = (dtype == 1 && C % 8 == 0) ? 2 : 1;
+  const int V = (dtype != 0 && C % 8 == 0) ? 2 : 1;
   const unsigned grid = brd_grid(R, C, dtype);
   if (dtype == 0) brd_bwd<float, 1><<<grid, 256, 0, st>>>((const float*)gh, (const float*)h, R, C, scale, (float*)ga, dbias);
   else if (dtype == 1 && V == 2) brd_bwd<__hip_bfloat16, 2><<<grid, 256, 0, st>>>((const __hip_bfloat16*)gh, (const __hip_bfloat16*)h, R, C, scale, (__hip_bfloat16*)ga, dbias);
   else if (dtype == 1) brd_bwd<__hip_bfloat16, 1><<<grid, 256, 0, st>>>((const __hip_bfloat16*)gh, (const __hip_bfloat16*)h, R, C, scale, (__hip_bfloat16*)ga, dbias);
+  else if (dtype == 2 && V == 2) brd_bwd<__half, 2><<<grid, 256, 0, st>>>((const __half*)gh, (const __half*)h, R, C, scale, (__half*)ga, dbias);
+  else if (dtype == 2) brd_bwd<__half, 1><<<grid, 256, 0, st>>>((const __half*)gh, (const __half*)h, R, C, scale, (__half*)ga, dbias);
   else return -1008;
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;

@@ -112,10 +112,10 @@ int prepare(State& s, hipStream_t st, void** ws) {
 
 Plan build(State& s, const Key& key);
 
-bool tuning_fp32() {      // also time fp32 plans (the MSDeformAttn projections), validated to 1e-5 of max |C| per element; default on since round 4
-  static const bool on = [] {        // (with every supporting kernel as a candidate it is worth 0.18 ms per step; the ranked dozen alone gave nothing)
-    const char* e = getenv("OCPG_GEMM_TUNE_FP32");
-    return !(e && e[0] == '0');
+bool tuning_fp32() {      // experiment switch (default off): also time fp32 plans, validated to 1e-5 of max |C| per element.  Round 4 tried it as
+  static const bool on = [] {        // the default with every supporting kernel as a candidate (-0.18 ms per step): one run of the fp32 case of
+    const char* e = getenv("OCPG_GEMM_TUNE_FP32");      // test_fused_linear_bias_relu_dropout then came out 2e-3 off -- a candidate that had passed the validation
+    return e && e[0] == '1';                            // and was wrong later.  fp32 is the parity-critical path (MSDeformAttn locations): default off again.
   }();
   return on;
 }

@@ -39,7 +39,7 @@ def _ffn_hidden(src, linear1, activation, drop):
         if torch.is_autocast_enabled("cuda"):
             dt = torch.get_autocast_dtype("cuda")
             x, w, b = x.to(dt), w.to(dt), b.to(dt)
-        if x.dtype == w.dtype and x.dtype in (torch.float32, torch.bfloat16) and w.shape[0] % 4 == 0:
+        if x.dtype == w.dtype and x.dtype in (torch.float32, torch.bfloat16, torch.float16) and w.shape[0] % 4 == 0:
             x2 = x.reshape(-1, x.shape[-1])
             splits = amp_cache._split_rows(x2.shape[0]) if amp_cache.SPLIT_K else 1
             h = fused_ln_func.LinearBiasReluDropout.apply(x2, w, b, drop.p if drop.training else 0.0, None, splits)

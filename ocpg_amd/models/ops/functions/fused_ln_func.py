@@ -18,7 +18,7 @@ from torch.autograd.function import once_differentiable
 from ...._lib import check, lib
 from .gemm_func import mm
 
-_DT = {torch.float32: 0, torch.bfloat16: 1}
+_DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 _calls = [0]
 _active = [None]            # the GraphRng whose capture is in progress (at most one per process)
 

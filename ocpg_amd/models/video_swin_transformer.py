@@ -289,6 +289,8 @@ class BasicLayer(nn.Module):
     def forward(self, x):
         """[B, C, D, H, W] -> [B, C', D, H', W']."""
         x = x.permute(0, 2, 3, 4, 1)
+        if not x.is_contiguous():      # (the previous stage / the patch embedding hand over channels-last memory: then this is a view --
+            x = x.contiguous()         #  a [B, C, D, H, W]-contiguous input made every op of the first block a strided one: 512 us per add at config #5)
         for blk in self.blocks:
             x = blk(x)
         if self.downsample is not None:
@@ -374,7 +376,7 @@ class VideoSwinTransformerBackbone(nn.Module):
         x = self.pos_drop(self.patch_embed(x))
         out = {}
         for idx, (layer, down) in enumerate(zip(self.layers, self.downsamples)):
-            x = layer(x.contiguous())
+            x = layer(x)               # (no .contiguous(): the stages work on [B, D, H, W, C] memory, which is what arrives here)
             out[str(idx)] = x
             if down is not None:
                 x = down(x.permute(0, 2, 3, 4, 1)).permute(0, 4, 1, 2, 3)

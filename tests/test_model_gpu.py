@@ -193,7 +193,7 @@ def _probe_keep_mask(rows, cols, p, rng, dev):
     return f.LinearBiasReluDropout.apply(ones, w, torch.zeros(cols, device=dev), p, rng, 1)
 
 
-@pytest.mark.parametrize("xdtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("xdtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("rows,c,p", [(1023, 256, 0.0), (37, 1024, 0.0), (5, 20, 0.0), (777, 256, 0.1), (64, 2048, 0.3)])
 def test_fused_dropout_add_layernorm(dev, xdtype, rows, c, p):
     """LayerNorm(res + dropout(x)) in one pass each way == the three-op formulation with the SAME mask (recovered from
@@ -223,7 +223,7 @@ def test_fused_dropout_add_layernorm(dev, xdtype, rows, c, p):
         assert (a - b_).abs().max().item() <= t * b_.abs().max().item() + 1e-6, (name, (a - b_).abs().max().item())
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("rows,p", [(8200, 0.0), (515, 0.1)])
 def test_fused_linear_bias_relu_dropout(dev, dtype, rows, p):
     """dropout(relu(x W^T + b)): GEMM + one fused pass == the three-op formulation with the same mask; gradients incl. bias."""
@@ -245,7 +245,7 @@ def test_fused_linear_bias_relu_dropout(dev, dtype, rows, p):
     for a, b_, name in zip(out[0], out[1], ("h", "gx", "gw", "gb")):
         if dtype == torch.float32:
             assert (a - b_).abs().max().item() <= 2e-5 * b_.abs().max().item() + 1e-6, (name, (a - b_).abs().max().item(), b_.abs().max().item())
-        else:   # bf16: the bias is added after (fused) vs before (addmm) the rounding of the GEMM result; a pre-activation within
+        else:   # bf16 / fp16: the bias is added after (fused) vs before (addmm) the rounding of the GEMM result; a pre-activation within
             #     an ulp of zero flips its ReLU (~0.25 % of the units here: ~3-5 % of the gradient norm) -> norm-relative bound
             assert (a - b_).norm().item() <= 6e-2 * b_.norm().item(), (name, (a - b_).norm().item(), b_.norm().item())
 

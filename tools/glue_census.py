@@ -10,6 +10,12 @@ import bench
 from ocpg_amd.models import build_model
 
 dev = torch.device("cuda:0")
+# CONFIG5=1: BASELINE config #5 (Video-Swin-B, 8 x 480 x 854, fp16 + GradScaler, 1 clip; text features precomputed)
+C5 = os.environ.get("CONFIG5") == "1"
+if C5:
+    bench.T_FRAMES, bench.HEIGHT, bench.WIDTH = 8, 480, 854
+    os.environ.setdefault("BACKBONE", "video_swin_b_p4w7")
+AMP = torch.float16 if C5 else torch.bfloat16
 args = bench.model_args(dev, os.environ.get("BACKBONE", "resnet101"), amp=True)
 model, crit, _ = build_model(args)
 model.to(dev); crit.to(dev)
@@ -18,8 +24,8 @@ for m in model.modules():
         m.to(memory_format=torch.channels_last)
 model.train(); crit.train()
 opt = bench.make_optimizer(model, args)
-make_samples, text, targets = bench.synthetic_batch(2, dev, 42)
-step = bench.EagerStep(model, model, crit, opt, make_samples, text, targets, args, torch.bfloat16)
+make_samples, text, targets = bench.synthetic_batch(1 if C5 else 2, dev, 42)
+step = bench.EagerStep(model, model, crit, opt, make_samples, text, targets, args, AMP)
 for _ in range(4):
     step()
 torch.cuda.synchronize()
