@@ -54,7 +54,10 @@ class LayerNorm(torch.nn.LayerNorm):
         if (x.is_cuda and torch.is_autocast_enabled("cuda") and len(self.normalized_shape) == 1 and self.normalized_shape[0] <= 1024
                 and self.elementwise_affine and self.bias is not None and x.dtype in _CODE and self.weight.dtype == torch.float32
                 and x.numel() > 0):
-            return LayerNormLP.apply(x, self.weight, self.bias, self.eps, torch.get_autocast_dtype("cuda"))
+            # fp32_out (set by the owner): the result stays fp32 -- a norm that STARTS a residual stream (Video-Swin's patch-embedding
+            # norm), where autocast's layer_norm returns fp32 too; the kernel still reads x in its own dtype: one pass, no casts
+            out = torch.float32 if getattr(self, "fp32_out", False) else torch.get_autocast_dtype("cuda")
+            return LayerNormLP.apply(x, self.weight, self.bias, self.eps, out)
         return super().forward(x)
 
 

@@ -25,7 +25,7 @@ from torch import nn
 
 from . import amp_cache, fallbacks
 
-from ..util.misc import NestedTensor
+from ..util.misc import NestedTensor, mask_key, resize_mask
 from .ops.functions.win_attn_func import window_attention
 from .ops.functions.layernorm_func import LayerNorm as _FusedLayerNorm, PermuteGather, StaticGather, permute_gather_ok
 from .position_encoding import build_position_encoding
@@ -303,7 +303,9 @@ class PatchEmbed3D(nn.Module):
         super().__init__()
         self.patch_size, self.in_chans, self.embed_dim = tuple(patch_size), in_chans, embed_dim
         self.proj = nn.Conv3d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
-        self.norm = norm_layer(embed_dim) if norm_layer is not None else None
+        self.norm = _lp_norm(norm_layer, embed_dim) if norm_layer is not None else None
+        if isinstance(self.norm, _FusedLayerNorm):
+            self.norm.fp32_out = True            # this norm's output IS the residual stream: fp32, as autocast's layer_norm returns it
 
     def forward(self, x):
         _, _, D, H, W = x.shape
@@ -314,7 +316,10 @@ class PatchEmbed3D(nn.Module):
             # temporal patch size 1 (every Video-Swin config of the reference): the Conv3d is a per-frame 2-D conv.
             # Same weights ([C, 3, 1, ph, pw], checkpoint-compatible), but MIOpen's 2-D path instead of its 3-D solvers.
             b, c, d, h, w = x.shape
-            y = F.conv2d(x.transpose(1, 2).reshape(b * d, c, h, w), self.proj.weight.squeeze(2), self.proj.bias, stride=(ph, pw))
+            xin = x.transpose(1, 2).reshape(b * d, c, h, w)
+            if xin.is_cuda:                      # channels-last in -> channels-last out: the token view below is then contiguous (no copy into the norm)
+                xin = xin.contiguous(memory_format=torch.channels_last)
+            y = F.conv2d(xin, self.proj.weight.squeeze(2), self.proj.bias, stride=(ph, pw))
             x = y.view(b, d, self.embed_dim, y.shape[-2], y.shape[-1]).transpose(1, 2)
         else:
             x = self.proj(x)
@@ -407,7 +412,7 @@ class BackboneBase(nn.Module):
         assert m is not None
         out = {}
         for name, x in self.body(tensor_list.tensors, num_frames).items():
-            out[name] = NestedTensor(x, F.interpolate(m[None].float(), size=x.shape[-2:]).to(torch.bool)[0])
+            out[name] = NestedTensor(x, resize_mask(m, x.shape[-2:]))        # memoised on the mask's valid extents, like the ResNet Joiner's
         return out
 
 
@@ -430,7 +435,10 @@ class Joiner(nn.Sequential):
     def forward(self, tensor_list: NestedTensor):
         t = tensor_list.tensors.shape[1]
         tensor_list.tensors = tensor_list.tensors.flatten(0, 1)          # NB: folds the caller's NestedTensor in place
+        key = mask_key(tensor_list.mask)
         tensor_list.mask = tensor_list.mask.flatten(0, 1)
+        if key is not None:             # (the tag of the padding mask's valid extents survives the fold: level masks and position
+            tensor_list.mask._ocpg_key = key      #  encodings are memoised on it, as in models/backbone.py's Joiner)
         xs = self[0](tensor_list, num_frames=t)
         out = [x for _, x in sorted(xs.items())]
         return out, [self[1](x).to(x.tensors.dtype) for x in out]
