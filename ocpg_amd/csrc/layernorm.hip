@@ -9,6 +9,7 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/ocpg_hip.h"
 
@@ -248,8 +249,10 @@ inline int status() {
 extern "C" {
 
 int ocpg_layernorm_blocks(long long rows) {
+  // (the backward leaves one partial row of dgamma / dbeta per workgroup for the caller to sum: the cap is also the height of that sum)
+  static const long long cap = [] { const char* e = getenv("OCPG_LN_BLOCKS"); const long long v = e && *e ? atoll(e) : 1024; return v < 1 ? 1 : v; }();
   const long long b = (rows + NT / 64 - 1) / (NT / 64);
-  return (int)(b < 1 ? 1 : b > 1024 ? 1024 : b);
+  return (int)(b < 1 ? 1 : b > cap ? cap : b);
 }
 
 int ocpg_layernorm_fwd(const void* x, int x_f32, const float* gamma, const float* beta, long long rows, int C, float eps, void* y, int y_f32,
