@@ -44,7 +44,7 @@ def post(m, i, o):
     ctx[m].pop().__exit__(None, None, None)
 for m in list(model.modules()) + list(crit.modules()):
     m.register_forward_pre_hook(pre); m.register_forward_hook(post)
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=os.environ.get("SHAPES") == "1") as prof:
     step()
     torch.cuda.synchronize()
 ev = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CPU]
@@ -104,3 +104,24 @@ for (label, name), (t, n) in aten.items():
 print("---- ATen by op")
 for k, (t, n) in sorted(byop.items(), key=lambda kv: -kv[1][0])[:40]:
     print("%8.1f us %5d  %s" % (t, n, k))
+if os.environ.get("SHAPES") == "1":
+    # ops that move few bytes per microsecond (strided / broadcast / tiny-row access patterns): candidates for a layout fix
+    print("---- slow ATen ops (>= 25 us, < 1.5 TB/s of operand bytes assuming fp32)")
+    slow = []
+    for e in ev:
+        dt = getattr(e, "self_device_time_total", 0) or 0
+        if dt < 25 or not e.name.startswith("aten::") or not getattr(e, "input_shapes", None):
+            continue
+        numel = 0
+        for sh in e.input_shapes:
+            if sh:
+                n = 1
+                for d in sh:
+                    n *= d
+                numel += n
+        gbs = numel * 4 / dt / 1e3
+        if gbs < 1500:
+            m = mod_of(e) or "?"
+            slow.append((dt, e.name, m, [list(sh) for sh in e.input_shapes if sh][:3], gbs))
+    for dt, name, m, shapes, gbs in sorted(slow, key=lambda t: -t[0])[:40]:
+        print("%7.1f us  %-24s %-40s %6.0f GB/s  %s" % (dt, name[:24], m[:40], gbs, shapes))
