@@ -517,6 +517,15 @@ int ocpg_groupnorm_cl2cl_bwd(const float* gy, const void* x, int x_dtype, const 
  * 112-114,151-153): g [M, H] fp32, order [M] int64 = argsort(idx), seg [T + 1] int64 = CSR offsets of every table row's segment in
  * `order`; out [T, H] fully written.  Segmented sum, no atomics (autograd's index_put(accumulate): ~40 colliding atomics per address). */
 int ocpg_gather_rows_bwd(const float* g, const long long* order, const long long* seg, int T, int H, float* out, void* stream);
+/* Video-Swin's relative-position bias in the two layouts the window-attention kernels read, straight from the table (round 4) --
+ * replaces `relative_position_bias_table[relative_position_index[:N, :N].reshape(-1)].reshape(N, N, -1).permute(2, 0, 1).contiguous()`
+ * (models/video_swin_transformer.py:151-153) and the transposed copy: bias[h][a][b] = table[idx[a * ldi + b]][h] (idx: the int64 index
+ * buffer, row stride ldi >= N), bias_t = its transpose over (a, b); both fp32 [H, N, N].  bwd: dtable [T, H] from the gradient of
+ * `bias` stored [H][N N] (transposed = 0) or from its transpose (transposed != 0: the attention backward's dS sum as it lies);
+ * order / seg: positions p = a N + b sorted by idx, segment offsets per table row (T + 1). */
+int ocpg_relpos_bias_fwd(const float* table, const long long* idx, int N, long long ldi, int H, float* bias, float* bias_t, void* stream);
+int ocpg_relpos_bias_bwd(const float* g, const long long* order, const long long* seg, int T, int H, int N, int transposed, float* out,
+                         void* stream);
 
 /* Row gather with padding slots: out [B, M, row] = idx[j] in [0, S) ? x [B, S, row][:, idx[j]] : 0; rows are row_bytes bytes (multiple of
  * 16, any dtype).  Video-Swin's pad + cyclic shift + window partition and its reverse (models/video_swin_transformer.py:171-199) are

@@ -71,6 +71,8 @@ SIGNATURES = {
     "ocpg_layernorm_fwd": [_vp, _int, _vp, _vp, ctypes.c_longlong, _int, ctypes.c_float, _vp, _int, _vp, _vp, _vp],
     "ocpg_layernorm_bwd": [_vp, _int, _vp, _int, _vp, _vp, _vp, ctypes.c_longlong, _int, _vp, _int, _vp, _vp, _vp],
     "ocpg_gather_rows_bwd": [_vp, _vp, _vp, _int, _int, _vp, _vp],
+    "ocpg_relpos_bias_fwd": [_vp, _vp, _int, ctypes.c_longlong, _int, _vp, _vp, _vp],
+    "ocpg_relpos_bias_bwd": [_vp, _vp, _vp, _int, _int, _int, _int, _vp, _vp],
     "ocpg_gather_rows_pad": [_vp, _vp] + [ctypes.c_longlong] * 4 + [_vp, _vp],
     "ocpg_graph_replace_memsets": [_vp, _vp],
     "ocpg_graph_stats": [_vp, _vp],

@@ -330,6 +330,73 @@ extern "C" int ocpg_gather_rows_bwd(const float* g, const long long* order, cons
   return e == hipSuccess ? 0 : -(int)e;
 }
 
+// ---- Video-Swin's relative-position bias (models/video_swin_transformer.py:151-153: table[index[:N, :N]].reshape(N, N, H).permute(2, 0, 1))
+// in the two layouts the attention kernels read, from the table directly (round 4): per block the chain was a gather to [N N, H], a
+// permuting copy to [H, N, N], a second copy for the transpose (and a transposing copy of the gradient on the way back): 100-200 us per
+// block at N = 392, 2.4 ms per config-#5 step.
+//   bias[h][a][b] = table[idx[a][b]][h]      bias_t[h][a][b] = table[idx[b][a]][h] = bias[h][b][a]          (all writes coalesced along b)
+namespace {
+
+__global__ __launch_bounds__(256) void relpos_bias(const float* __restrict__ table, const long long* __restrict__ idx, int N, long long ldi, int H,
+                                                   float* __restrict__ bias, float* __restrict__ bias_t) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  const int P = N * N;
+  if (q >= P) return;
+  const int a = q / N, b = q - a * N;
+  const float* r1 = table + idx[a * ldi + b] * H;
+  const float* r2 = table + idx[b * ldi + a] * H;
+  for (int h = 0; h < H; ++h) {
+    bias[(long long)h * P + q] = r1[h];
+    bias_t[(long long)h * P + q] = r2[h];
+  }
+}
+
+// dtable[t][h] = sum over the positions p = a N + b with idx[a][b] == t of g[h][pos(p)]: g is the gradient of `bias` stored [H][N N]
+// (pos(p) = p), or -- transposed != 0 -- of its transpose, i.e. the attention backward's own dS sum (pos(p) = b N + a: no transposing copy)
+__global__ __launch_bounds__(256) void relpos_bias_bwd(const float* __restrict__ g, const long long* __restrict__ order, const long long* __restrict__ seg,
+                                                       int T, int H, int N, int transposed, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= T * H) return;
+  const int t = i / H, h = i - t * H;
+  const float* gh = g + (long long)h * N * N;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  long long p = seg[t];
+  const long long pe = seg[t + 1];
+  auto pos = [&](long long o) { return transposed ? (o % N) * N + o / N : o; };
+  for (; p + 8 <= pe; p += 8) {
+    long long o[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = order[p + k];
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = gh[pos(o[k])];
+    s0 += v[0] + v[4], s1 += v[1] + v[5], s2 += v[2] + v[6], s3 += v[3] + v[7];
+  }
+  for (; p < pe; ++p) s0 += gh[pos(order[p])];
+  out[i] = (s0 + s1) + (s2 + s3);
+}
+
+}  // namespace
+
+extern "C" int ocpg_relpos_bias_fwd(const float* table, const long long* idx, int N, long long ldi, int H, float* bias, float* bias_t, void* stream) {
+  if (N <= 0 || H <= 0 || ldi < N) return -1003;
+  if (!table || !idx) return -1001;
+  if (!bias || !bias_t) return -1006;
+  relpos_bias<<<(N * N + 255) / 256, 256, 0, (hipStream_t)stream>>>(table, idx, N, ldi, H, bias, bias_t);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+extern "C" int ocpg_relpos_bias_bwd(const float* g, const long long* order, const long long* seg, int T, int H, int N, int transposed, float* out,
+                                    void* stream) {
+  if (T <= 0 || H <= 0 || N <= 0) return -1004;
+  if (!g || !order || !seg) return -1001;
+  if (!out) return -1008;
+  relpos_bias_bwd<<<(T * H + 255) / 256, 256, 0, (hipStream_t)stream>>>(g, order, seg, T, H, N, transposed, out);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
 // ---- row gather with padding slots: out[b, j, :] = idx[j] < S ? x[b, idx[j], :] : 0, rows moved as 16-byte segments (any dtype).
 // Video-Swin's pad + cyclic shift + window partition (and its reverse) is one such gather (models/video_swin_transformer.py:
 // 171-199 does pad, roll, view/permute, and the mirror image); because every token sits in exactly one window slot, the backward

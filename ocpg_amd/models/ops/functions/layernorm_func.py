@@ -90,6 +90,40 @@ class StaticGather(Function):
         return out.to(g.dtype), None, None
 
 
+class RelPosBias(Function):
+    """(bias, bias_t) [H, N, N] fp32 = table[index[:N, :N]] as [H, N, N] and its transpose over the two token axes, one launch
+    (csrc/layernorm.hip relpos_bias); backward: a segmented sum straight from the gradient of `bias` -- or from its transpose when that is
+    what lies contiguous (the attention backward hands `ds.sum(0).transpose(1, 2)`)."""
+
+    @staticmethod
+    def forward(ctx, table, index2d, plan):
+        n = index2d.shape[0]
+        t, h = table.shape
+        assert table.dtype == torch.float32 and table.is_contiguous() and index2d.dtype == torch.int64 and index2d.stride(1) == 1
+        bias = torch.empty((h, n, n), dtype=torch.float32, device=table.device)
+        bias_t = torch.empty_like(bias)
+        check(lib().ocpg_relpos_bias_fwd(table.data_ptr(), index2d.data_ptr(), n, index2d.stride(0), h, bias.data_ptr(), bias_t.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream), "ocpg_relpos_bias_fwd")
+        ctx.plan, ctx.shape, ctx.n = plan, (t, h), n
+        ctx.mark_non_differentiable(bias_t)
+        return bias, bias_t
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g, _gt):
+        order, seg = ctx.plan
+        t, h = ctx.shape
+        g = g.float()
+        if g.transpose(1, 2).is_contiguous() and not g.is_contiguous():
+            src, transposed = g.transpose(1, 2), 1
+        else:
+            src, transposed = g.contiguous(), 0
+        out = torch.empty((t, h), dtype=torch.float32, device=g.device)
+        check(lib().ocpg_relpos_bias_bwd(src.data_ptr(), order.data_ptr(), seg.data_ptr(), t, h, ctx.n, transposed, out.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream), "ocpg_relpos_bias_bwd")
+        return out, None, None
+
+
 class PermuteGather(Function):
     """out[b, j] = x[b, fwd_idx[j]] (a slot whose index is outside [0, S) reads zeros); `bwd_idx` [S] is the inverse map (for every source
     row the slot that holds it, or -1): the backward is the same kernel with the roles swapped."""

@@ -15,7 +15,7 @@ _DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 
 class WindowAttentionFunction(Function):
     @staticmethod
-    def forward(ctx, qkv, bias, region, scale, num_windows):
+    def forward(ctx, qkv, bias, region, scale, num_windows, bias_t=None):
         """qkv [BW, N, 3, H, 32]; bias [H, N, N] (fp32); region [NW, N] int32 or None -> out [BW, N, H*32]."""
         if not qkv.is_cuda:
             raise RuntimeError("WindowAttentionFunction: qkv must be a GPU tensor: Not implemented on the CPU")
@@ -25,7 +25,8 @@ class WindowAttentionFunction(Function):
         bw, n, three, h, hd = qkv.shape
         assert three == 3
         bias = bias.float().contiguous()
-        bias_t = bias.transpose(1, 2).contiguous()
+        if bias_t is None or bias_t.dtype != torch.float32 or not bias_t.is_contiguous() or bias_t.shape != bias.shape:
+            bias_t = bias.transpose(1, 2).contiguous()        # (models/video_swin_transformer.py hands the transposed table along: RelPosBias)
         out = torch.empty((bw, n, h * hd), dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty((bw, h, n), dtype=torch.float32, device=qkv.device)
         with torch.cuda.device(qkv.device):
@@ -56,7 +57,7 @@ class WindowAttentionFunction(Function):
                                                   ds.data_ptr() if ds is not None else None, _DT[qkv.dtype], stream_ptr())
             if rc == 0:
                 dbias = ds.sum(0, dtype=torch.float32).transpose(1, 2) if ds is not None else None
-                return dqkv, dbias, None, None, None
+                return dqkv, dbias, None, None, None, None
             if rc != -2000:
                 check(rc, "ocpg_win_attn_bwd_mfma")
         dbias_t = torch.zeros_like(bias_t) if ctx.needs_input_grad[1] else None
@@ -67,8 +68,9 @@ class WindowAttentionFunction(Function):
                                           dbias_t.data_ptr() if dbias_t is not None else None, _DT[qkv.dtype], stream_ptr()),
                   "ocpg_win_attn_bwd")
         dbias = dbias_t.transpose(1, 2) if dbias_t is not None else None
-        return dqkv, dbias, None, None, None
+        return dqkv, dbias, None, None, None, None
 
 
-def window_attention(qkv, bias, region, scale, num_windows):
-    return WindowAttentionFunction.apply(qkv, bias, region, scale, num_windows)
+def window_attention(qkv, bias, region, scale, num_windows, bias_t=None):
+    """bias_t (optional, no gradient): bias.transpose(1, 2) already contiguous."""
+    return WindowAttentionFunction.apply(qkv, bias, region, scale, num_windows, bias_t)

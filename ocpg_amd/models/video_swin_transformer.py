@@ -27,7 +27,7 @@ from . import amp_cache, fallbacks
 
 from ..util.misc import NestedTensor, mask_key, resize_mask
 from .ops.functions.win_attn_func import window_attention
-from .ops.functions.layernorm_func import LayerNorm as _FusedLayerNorm, PermuteGather, StaticGather, permute_gather_ok
+from .ops.functions.layernorm_func import LayerNorm as _FusedLayerNorm, PermuteGather, RelPosBias, StaticGather, permute_gather_ok
 from .position_encoding import build_position_encoding
 
 
@@ -130,6 +130,7 @@ def _lp_norm(norm_layer, dim):
 
 
 _FUSED_LN = os.environ.get("OCPG_FUSED_SWIN_LN", "1") != "0"
+_RELPOS_KERNEL = os.environ.get("OCPG_RELPOS_KERNEL", "1") != "0"     # A/B switch: relative-position bias (both layouts) from the table in one launch
 
 
 class WindowAttention3D(nn.Module):
@@ -155,8 +156,17 @@ class WindowAttention3D(nn.Module):
 
     def relative_position_bias(self, n):
         """[heads, N, N]; the index table is sliced [:N, :N] for a clamped window exactly as the reference does."""
-        idx = self.relative_position_index[:n, :n].reshape(-1)
         table = self.relative_position_bias_table
+        self._bias_t = None
+        if _RELPOS_KERNEL and table.is_cuda and table.dtype == torch.float32 and table.is_contiguous():
+            # both layouts the attention kernels read, from the table, in one launch (csrc/layernorm.hip relpos_bias)
+            idx2 = self.relative_position_index[:n, :n]
+            plan = self.__dict__.get("_relpos_plan")
+            if plan is None or plan[0] != (n, table.device):
+                plan = self.__dict__["_relpos_plan"] = ((n, table.device), StaticGather.plan(idx2.reshape(-1), table.shape[0]))
+            bias, self._bias_t = RelPosBias.apply(table, idx2, plan[1])
+            return bias
+        idx = self.relative_position_index[:n, :n].reshape(-1)
         if table.is_cuda and table.dtype == torch.float32 and table.requires_grad and torch.is_grad_enabled():
             plan = self.__dict__.get("_gather_plan")                     # the index is a buffer: sorted by destination once per N
             if plan is None or plan[0] != (n, table.device):
@@ -174,7 +184,7 @@ class WindowAttention3D(nn.Module):
         if (x.is_cuda and c // h == 32 and (self.attn_drop.p == 0.0 or not self.training) and (mask is None or region is not None)
                 and not _GENERIC_ATTENTION):
             nw = region.shape[0] if region is not None else 1
-            out = window_attention(qkv.view(bw, n, 3, h, c // h), bias, region, self.scale, nw)      # csrc/win_attn.hip
+            out = window_attention(qkv.view(bw, n, 3, h, c // h), bias, region, self.scale, nw, self.__dict__.pop("_bias_t", None))      # csrc/win_attn.hip
             return self.proj_drop(self.proj(out))
         # generic path (CPU unit tests of the host logic, head_dim != 32, attention dropout): torch's fused SDPA
         fallbacks.note("WindowAttention3D", "generic attention forced (OCPG_GENERIC_WINDOW_ATTENTION)" if _GENERIC_ATTENTION else
