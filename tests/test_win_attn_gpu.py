@@ -83,3 +83,27 @@ def test_fused_layernorm_low_precision(dev, xdt, odt, rows, c):
     assert (gx.float() - rx).abs().max().item() <= eps_x * rx.abs().max().item() + 1e-5
     assert (gw - rw).abs().max().item() <= 2e-5 * rw.abs().max().item() + 1e-4
     assert (gb - rb).abs().max().item() <= 2e-5 * rb.abs().max().item() + 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,heads", [(392, 4), (245, 3), (37, 16)])
+def test_relative_position_bias_kernel_equals_table_lookup(n, heads):
+    """csrc/layernorm.hip relpos_bias (round 4): bias and its transpose from the table in one launch == the reference's
+    table[index[:N, :N].reshape(-1)].reshape(N, N, -1).permute(2, 0, 1) (video_swin_transformer.py:151-153), full and clamped windows; the
+    table gradient from a contiguous gradient and from one whose TRANSPOSE is contiguous (what the attention backward hands back)."""
+    import ocpg_amd.models.video_swin_transformer as vs
+    dev = torch.device("cuda:0")
+    torch.manual_seed(n)
+    wa = vs.WindowAttention3D(32 * heads, (8, 7, 7), heads, qkv_bias=True).to(dev)
+    with torch.no_grad():
+        wa.relative_position_bias_table.normal_()
+    idx = wa.relative_position_index[:n, :n].reshape(-1)
+    want = wa.relative_position_bias_table[idx].view(n, n, -1).permute(2, 0, 1)
+    bias = wa.relative_position_bias(n)
+    bias_t = wa.__dict__.pop("_bias_t")
+    assert bias.is_contiguous() and bias_t.is_contiguous()
+    assert torch.equal(bias, want) and torch.equal(bias_t, want.transpose(1, 2))
+    for g in (torch.randn(heads, n, n, device=dev), torch.randn(heads, n, n, device=dev).transpose(1, 2)):
+        got, = torch.autograd.grad(bias, wa.relative_position_bias_table, g, retain_graph=True)
+        ref, = torch.autograd.grad(want, wa.relative_position_bias_table, g, retain_graph=True)
+        assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-6
