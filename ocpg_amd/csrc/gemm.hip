@@ -229,7 +229,9 @@ Plan build(State& s, const Key& key) {
   // OCPG_GEMM_TUNE_ALL (default 1, round 4): the heuristic ranks by a model; time EVERY Tensile kernel that supports the problem
   // (hipblaslt_ext::getAllAlgos + matmulIsAlgoSupported, same validation against the default as the ranked ones).  The list order is
   // the library's own, so the candidate indices stay comparable between ranks (gemm_sync).
-  if (tune_all() && tuning() && (key.dtype != 0 || tuning_fp32()) && p.ncand >= 1) {
+  // Not for products of fewer than four depth-64 K iterations: both times a validated kernel was later seen wrong (round 3's Custom_
+  // kernels, round 4's fp32 candidate) the product was tests' [8200 x 64] x [64 x 1032] -- short-K problems keep the ranked list.
+  if (tune_all() && tuning() && (key.dtype != 0 || tuning_fp32()) && p.ncand >= 1 && key.k >= 256) {
     std::vector<hipblasLtMatmulHeuristicResult_t> all;
     if (hipblaslt_ext::getAllAlgos(s.handle, hipblaslt_ext::GemmType::HIPBLASLT_GEMM, opa, opb, in, in, out, out, HIPBLAS_COMPUTE_32F, all) ==
         HIPBLAS_STATUS_SUCCESS) {

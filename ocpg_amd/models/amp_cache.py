@@ -431,6 +431,7 @@ class TokenLinearFunction(torch.autograd.Function):
         return gx, gw, gb
 
 
+TOKEN_LINEAR_MIN_ROWS = int(os.environ.get("OCPG_TOKEN_LINEAR_MIN_ROWS", "8192"))     # rows from which a Linear goes through TokenLinearFunction (plan-cache GEMMs, row-split weight gradient)
 SMALL_LINEAR_F32 = os.environ.get("OCPG_SMALL_LINEAR_F32", "1") != "0"     # A/B switch: the fp32 islands' few-row Linears too (csrc/small_linear_f32.hip)
 SMALL_LINEAR = os.environ.get("OCPG_SMALL_LINEAR", "1") != "0"     # A/B switch: few-row Linears as one launch each way (csrc/small_linear.hip)
 
@@ -545,7 +546,7 @@ def linear(x, w, b):
         return SmallLinearFunction.apply(x, w, b)
     if _small_linear_f32_ok(x, w, b):
         return SmallLinearF32Function.apply(x, w, b)
-    if SPLIT_K and x.is_cuda and w.requires_grad and x.numel() >= 8192 * k and torch.is_grad_enabled():
+    if SPLIT_K and x.is_cuda and w.requires_grad and x.numel() >= TOKEN_LINEAR_MIN_ROWS * k and torch.is_grad_enabled():
         if torch.is_autocast_enabled("cuda"):
             dt = torch.get_autocast_dtype("cuda")
             x, w, b = x.to(dt), w.to(dt), None if b is None else b.to(dt)
