@@ -985,21 +985,21 @@ def main():
                                 frac=dom["algorithmic_bytes"] / us0 / 1e3 / HBM_PEAK_GBS, launches_timed=rk["n"],
                                 timed_in="this process, after the timed steps: the entry point on the model's initial ring offsets, calls back to back "
                                          "(HIP events on the launch stream); launch_us_in_eager_steps = the same call inside the extra eager steps")
-                # HEADLINE roofline row: the same entry point on perturbed ("trained-like") offsets -- +3 px gaussian noise, 5 % of
-                # the samples anywhere in the map -- through the per-call selection, which moves such a call site to the output-tiled kernels
+                # `roofline` stays the kernel the timed steps launch (the contract's definition); next to it the same entry point
+                # on perturbed ("trained-like") offsets -- +3 px gaussian noise, 5 % of the samples anywhere in the map -- through the
+                # per-call selection, which moves such a call site to the output-tiled kernels
                 tk = time_msda_kernels(nfr, device, noise=3.0, outliers=0.05)
                 pk, selinfo = tk.get("bwd_enc_value"), tk.get("selection", {"path": "column", "far_share": None})
                 if pk and pk["n"]:
                     us = pk["ms"] / pk["n"] * 1e3
                     fam = selinfo["path"]
-                    line["roofline"] = {"bound": "hbm", "kernel": " + ".join(GV_KERNELS[fam]) + f" (selected: {fam} family) -- " + what,
+                    line["roofline_trained_like_offsets"] = {"bound": "hbm", "kernel": " + ".join(GV_KERNELS[fam]) + f" (selected: {fam} family) -- " + what,
                                         "offsets": "ring + N(0, 3 px) + 5 % uniform (trained-like)", "far_share_seen": selinfo["far_share"],
                                         "achieved": dom["algorithmic_bytes"] / us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": dom["algorithmic_bytes"] / us / 1e3 / HBM_PEAK_GBS,
                                         "traffic": pmc_traffic(GV_KERNELS[fam], "trained", nfr), "launch_us": us,
                                         "algorithmic_bytes": dom["algorithmic_bytes"], "launches_timed": pk["n"],
                                         "timed_in": "this process, after the timed steps: the entry point on synthetic trained-like offsets (HIP events on the launch stream)"}
-                    line["roofline_ring_offsets"] = ring
         if rows:
             line["kernels"] = rows[:16]
         from ocpg_amd.models import fallbacks

@@ -9,5 +9,5 @@ timeout -k 10 600 python3 bench.py > gpurun_out/r4/bench_$tag.json 2> gpurun_out
 python3 - <<PY
 import json
 l=json.load(open("gpurun_out/r4/bench_$tag.json"))
-print({k:l[k] for k in ("value","ms_per_step")}, l.get("b1"), l.get("roofline"), l.get("roofline_perturbed_offsets"))
+print({k:l[k] for k in ("value","ms_per_step")}, l.get("b1"), l.get("roofline"), l.get("roofline_trained_like_offsets"))
 PY
