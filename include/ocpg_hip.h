@@ -212,6 +212,14 @@ int ocpg_conv3x3_mfma_dgrad_w(const void* dy, const void* w, const void* mask_y,
  * ocpg_im2col3x3_nhwc + a row-split ocpg_gemm): gz [N,Ho,Wo,Cout] bf16 (the gradient after the BN / ReLU backward), x [N,H,W,Cin] bf16 ->
  * part [S][Cout][3][3][Cin] bf16, S = ocpg_conv3x3_mfma_wgrad_splits(...) partial sums over ranges of output rows (the caller adds them:
  * gw = sum_z part[z]).  Cin % 8 or Cout % 8 != 0: -2000. */
+/* The same forward / input gradient with the K chain split over the grid for launches of few tiles and long K (round 4: ResNet layer3 /
+ * layer4 at 1-2 clips per step): `splits` = ocpg_conv3x3_mfma_body_splits(rows, GEMM columns, K channels) (1 = use the un-split entry);
+ * part: fp32 scratch [splits][rows][columns]; the summing pass applies the epilogue (BN affine + ReLU; scale + mask of the layer in front). */
+int ocpg_conv3x3_mfma_body_splits(long long M, int ncols, int kchannels);
+int ocpg_conv3x3_mfma_fwd_bn_splitk(const void* x, const void* w, const float* scale, const float* shift, int relu, int N, int H, int W, int Cin,
+                                    int Cout, int stride, int splits, float* part, void* y, void* stream);
+int ocpg_conv3x3_mfma_dgrad_w_splitk(const void* dy, const void* w, const void* mask_y, const float* scale, int N, int H, int W, int Cin,
+                                     int Cout, int stride, int splits, float* part, void* dx, void* stream);
 int ocpg_conv3x3_mfma_wgrad_splits(int N, int H, int W, int Cin, int Cout, int stride);
 int ocpg_conv3x3_mfma_wgrad(const void* gz, const void* x, int N, int H, int W, int Cin, int Cout, int stride, void* part, void* stream);
 

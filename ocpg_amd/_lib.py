@@ -39,6 +39,9 @@ SIGNATURES = {
     "ocpg_conv3x3_mfma_dgrad_w": [_vp, _vp, _vp, _vp] + [_int] * 6 + [_vp, _vp],
     "ocpg_conv3x3_mfma_splits": [_int] * 6,
     "ocpg_conv3x3_mfma_wgrad_splits": [_int] * 6,
+    "ocpg_conv3x3_mfma_body_splits": [ctypes.c_longlong, _int, _int],
+    "ocpg_conv3x3_mfma_fwd_bn_splitk": [_vp, _vp, _vp, _vp] + [_int] * 8 + [_vp, _vp, _vp],
+    "ocpg_conv3x3_mfma_dgrad_w_splitk": [_vp, _vp, _vp, _vp] + [_int] * 7 + [_vp, _vp, _vp],
     "ocpg_conv3x3_mfma_wgrad": [_vp, _vp] + [_int] * 6 + [_vp, _vp],
     "ocpg_conv3x3_mfma_fwd_splitk": [_vp, _vp, _vp] + [_int] * 7 + [_vp, _vp, _int, _vp, _vp],
     "ocpg_gemm": [_vp, _vp, _vp, _vp] + [_int] * 4 + [ctypes.c_longlong] * 10 + [ctypes.c_float, ctypes.c_float, _vp],
@@ -125,7 +128,7 @@ SIGNATURES = {
 
 # ---- optional live kernel timing (bench.py): HIP events on the launch stream around every library call ----------
 _TIMING = {"on": False, "events": []}
-_UNTIMED = ("ocpg_conv3x3_mfma_wgrad_splits", "ocpg_window_sums3x3_cl_bands", "ocpg_lfm_dft_supported", "ocpg_lfm_dft_split", "ocpg_conv3x3_mfma_splits", "ocpg_gemm_set_tuning", "ocpg_gemm_export_picks", "ocpg_gemm_import_picks", "ocpg_colsum_blocks", "ocpg_mso_wgrad_rows", "ocpg_gemm_plans", "ocpg_gemm_tuned", "ocpg_gemm_tune_rejected", "ocpg_bias_relu_dropout_bwd_slots", "ocpg_dropout_add_ln_bwd_slots", "ocpg_groupnorm_cl_work")
+_UNTIMED = ("ocpg_conv3x3_mfma_body_splits", "ocpg_conv3x3_mfma_wgrad_splits", "ocpg_window_sums3x3_cl_bands", "ocpg_lfm_dft_supported", "ocpg_lfm_dft_split", "ocpg_conv3x3_mfma_splits", "ocpg_gemm_set_tuning", "ocpg_gemm_export_picks", "ocpg_gemm_import_picks", "ocpg_colsum_blocks", "ocpg_mso_wgrad_rows", "ocpg_gemm_plans", "ocpg_gemm_tuned", "ocpg_gemm_tune_rejected", "ocpg_bias_relu_dropout_bwd_slots", "ocpg_dropout_add_ln_bwd_slots", "ocpg_groupnorm_cl_work")
 
 
 def enable_kernel_timing(on=True):

@@ -488,15 +488,35 @@ extern "C" int ocpg_conv3x3_mfma_dgrad_w(const void* dy, const void* w, const vo
 
 namespace {
 
-// out[m][c] = sum_z part[z][m][c] + bias[c]  (out_dt 0 fp32 / 1 bf16)
+// out[m][c] = act((sum_z part[z][m][c]) * scale[c] + bias[c]), zeroed where mask[m][c] <= 0  (out_dt 0 fp32 / 1 bf16; scale / bias / mask may
+// be NULL; act = ReLU when relu != 0): the epilogues of the un-split kernel (conv bias; frozen-BN affine + ReLU; the layer in front's
+// BN + ReLU backward) applied by the summing pass
 __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ part, const float* __restrict__ bias, int splits, long long MC, int Cout,
-                                                       void* __restrict__ out, int out_dt) {
+                                                       void* __restrict__ out, int out_dt, const float* __restrict__ scale = nullptr, int relu = 0,
+                                                       const __hip_bfloat16* __restrict__ mask = nullptr) {
   const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= MC) return;
-  float4 a = bias ? *reinterpret_cast<const float4*>(bias + i % Cout) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int z = 0; z < splits; ++z) {
     const float4 v = *reinterpret_cast<const float4*>(part + (long long)z * MC + i);
     a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  const int c = (int)(i % Cout);
+  if (scale) {
+    const float4 sv = *reinterpret_cast<const float4*>(scale + c);
+    a.x *= sv.x; a.y *= sv.y; a.z *= sv.z; a.w *= sv.w;
+  }
+  if (bias) {
+    const float4 bv = *reinterpret_cast<const float4*>(bias + c);
+    a.x += bv.x; a.y += bv.y; a.z += bv.z; a.w += bv.w;
+  }
+  if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+  if (mask) {
+    const ushort4 mk = *reinterpret_cast<const ushort4*>(reinterpret_cast<const unsigned short*>(mask) + i);      // bf16 > 0 <=> its bits as a signed short > 0
+    if (!((short)mk.x > 0)) a.x = 0.f;
+    if (!((short)mk.y > 0)) a.y = 0.f;
+    if (!((short)mk.z > 0)) a.z = 0.f;
+    if (!((short)mk.w > 0)) a.w = 0.f;
   }
   if (out_dt == 0) {
     *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + i) = a;
@@ -541,6 +561,69 @@ extern "C" int ocpg_conv3x3_mfma_fwd_splitk(const void* x, const void* w, const 
       (const __hip_bfloat16*)x, (const __hip_bfloat16*)w, nullptr, nullptr, 0, g, reinterpret_cast<__hip_bfloat16*>(part), (__hip_bfloat16*)cols);
   const long long MC = g.M * Cout;
   k_splitk_reduce<<<(unsigned)((MC / 4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(part, bias, splits, MC, Cout, y, out_dt);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// ---- split K for the ResNet body (round 4): at 2 (1) clips per step a layer3 / layer4 convolution is 300-600 (150-300) workgroups each
+// walking 36-72 K steps one after the other -- a latency chain (the launch takes the SAME 45 us at 1 and at 2 clips per step).  With the
+// 64-channel chunks of K split over blockIdx.z the chains are 18 steps and three times as many workgroups overlap; the summing pass
+// carries the epilogue.  splits: ocpg_conv3x3_mfma_body_splits (1 = the un-split kernel is the better one).
+extern "C" int ocpg_conv3x3_mfma_body_splits(long long M, int ncols, int kchannels) {
+  if (M <= 0 || ncols <= 0 || kchannels <= 0 || kchannels % BK != 0 || ncols % 4 != 0) return 1;
+  static const int mode = [] { const char* e = std::getenv("OCPG_CONV3X3_SPLITK"); return e ? std::atoi(e) : -1; }();       // 0: never, n > 1: force n where it divides
+  const long long tiles = ((M + BM - 1) / BM) * ((ncols + 63) / 64);
+  const int chunks = kchannels / BK;
+  if (mode == 0) return 1;
+  if (mode > 1) return chunks % mode == 0 ? mode : 1;
+  if (tiles > 640) return 1;
+  int best = 1;
+  for (int sgl = 2; sgl <= chunks; ++sgl)
+    if (chunks % sgl == 0 && chunks / sgl >= 2 && tiles * sgl <= 1280) best = sgl;
+  return best;
+}
+
+// y = act(conv(x, w) * scale + shift) as in ocpg_conv3x3_mfma_fwd, K split `splits` ways; part: fp32 scratch [splits][N*Ho*Wo][Cout]
+extern "C" int ocpg_conv3x3_mfma_fwd_bn_splitk(const void* x, const void* w, const float* scale, const float* shift, int relu, int N, int H, int W, int Cin,
+                                               int Cout, int stride, int splits, float* part, void* y, void* stream) {
+  if (N < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return -1006;
+  if ((stride != 1 && stride != 2) || Cin % BK != 0 || Cout % 4 != 0 || splits < 2 || (Cin / BK) % splits != 0) return -2000;
+  if (N == 0) return 0;
+  if (!x) return -1001;
+  if (!w) return -1002;
+  if (!part) return -1013;
+  if (!y) return -1014;
+  ConvGeom g;
+  g.N = N; g.H = (H - 1) / stride + 1; g.W = (W - 1) / stride + 1; g.C = Cin; g.Hs = H; g.Ws = W; g.Cout = Cout; g.stride = stride;
+  g.M = (long long)N * g.H * g.W;
+  const unsigned mt = (unsigned)((g.M + BM - 1) / BM);
+  conv3x3_mfma<false, 64, true><<<dim3(mt, (unsigned)((Cout + 63) / 64), (unsigned)splits), NT, 0, (hipStream_t)stream>>>(
+      (const __hip_bfloat16*)x, (const __hip_bfloat16*)w, nullptr, nullptr, 0, g, reinterpret_cast<__hip_bfloat16*>(part), nullptr);
+  const long long MC = g.M * Cout;
+  k_splitk_reduce<<<(unsigned)((MC / 4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(part, shift, splits, MC, Cout, y, 1, scale, relu);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// dx as in ocpg_conv3x3_mfma_dgrad_w (the convolution's own weight; mask_y / scale as there), K (= the output channels) split `splits` ways;
+// part: fp32 scratch [splits][N*H*W][Cin]
+extern "C" int ocpg_conv3x3_mfma_dgrad_w_splitk(const void* dy, const void* w, const void* mask_y, const float* scale, int N, int H, int W, int Cin,
+                                                int Cout, int stride, int splits, float* part, void* dx, void* stream) {
+  if (N < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return -1006;
+  if ((stride != 1 && stride != 2) || Cout % BK != 0 || Cin % 8 != 0 || splits < 2 || (Cout / BK) % splits != 0) return -2000;
+  if (N == 0) return 0;
+  if (!dy) return -1001;
+  if (!w) return -1002;
+  if (!part) return -1012;
+  if (!dx) return -1013;
+  ConvGeom g;
+  g.N = N; g.H = H; g.W = W; g.C = Cout; g.Hs = (H - 1) / stride + 1; g.Ws = (W - 1) / stride + 1; g.Cout = Cin; g.stride = stride;
+  g.M = (long long)N * H * W;
+  const unsigned mt = (unsigned)((g.M + BM - 1) / BM);
+  conv3x3_mfma<true, 64, true, true><<<dim3(mt, (unsigned)((Cin + 63) / 64), (unsigned)splits), NT, 0, (hipStream_t)stream>>>(
+      (const __hip_bfloat16*)dy, (const __hip_bfloat16*)w, nullptr, nullptr, 0, g, reinterpret_cast<__hip_bfloat16*>(part), nullptr);
+  const long long MC = g.M * Cin;
+  k_splitk_reduce<<<(unsigned)((MC / 4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(part, nullptr, splits, MC, Cin, dx, 1, scale, 0, (const __hip_bfloat16*)mask_y);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }

@@ -300,6 +300,7 @@ def eligible3x3_mfma(x, conv):
             and x.shape[1] % 64 == 0 and conv.out_channels % 64 == 0 and x.shape[1] >= _MFMA_MIN_C and conv.out_channels >= _MFMA_MIN_C)
 
 
+BODY_SPLITK = os.environ.get("OCPG_CONV3X3_SPLITK", "0") != "0"     # opt-in (-1 = where the tile grid is small, n = force n): split-K forward / input gradient of the body's 3x3 convs; measured +0.45 ms per step at 2 clips, neutral at 1 (r4)
 WGRAD_OWN = os.environ.get("OCPG_WGRAD_OWN", "1") != "0"     # A/B switch: conv3x3_mfma's weight gradient by csrc/conv3x3_wgrad.hip (0 = im2col + row-split GEMM)
 DGRAD_OWN_WEIGHT = os.environ.get("OCPG_DGRAD_OWN_WEIGHT", "1") != "0"     # A/B switch: conv3x3_mfma's input gradient reads the weight untransposed
 _MFMA_MIN_C = int(os.environ.get("OCPG_MFMA_CONV3X3_MIN_C", "128"))     # 64 also serves layer1 (frozen: forward only), measured 0.08 ms/step SLOWER than MIOpen there (r4)
@@ -323,8 +324,14 @@ class Conv3x3MfmaBNAct(Function):
         # the forward kernel gathers exactly the rows of the patch matrix the weight gradient needs: kept (44 MB per layer3 conv, 1.4 GB over
         # the ResNet-101 body at 10 frames) instead of re-gathered by an im2col launch in the backward
         cols = torch.empty((n * ho * wo, 9 * c), dtype=x.dtype, device=x.device) if (FWD_COLS and ctx.needs_input_grad[1]) else None
-        check(lib().ocpg_conv3x3_mfma_fwd_cols(x.data_ptr(), w2.data_ptr(), scale.data_ptr(), shift.data_ptr(), int(relu), n, h, wd, c, co, stride,
-                                               y.data_ptr(), None if cols is None else cols.data_ptr(), st), "ocpg_conv3x3_mfma_fwd_cols")
+        sp = int(lib().ocpg_conv3x3_mfma_body_splits(n * ho * wo, co, c)) if (BODY_SPLITK and cols is None) else 1
+        if sp > 1:      # few tiles, long K: the K chain split over the grid, the BN + ReLU epilogue in the summing pass (csrc/conv3x3_mfma.hip)
+            part = torch.empty((sp, n * ho * wo, co), dtype=torch.float32, device=x.device)
+            check(lib().ocpg_conv3x3_mfma_fwd_bn_splitk(x.data_ptr(), w2.data_ptr(), scale.data_ptr(), shift.data_ptr(), int(relu), n, h, wd, c, co, stride,
+                                                        sp, part.data_ptr(), y.data_ptr(), st), "ocpg_conv3x3_mfma_fwd_bn_splitk")
+        else:
+            check(lib().ocpg_conv3x3_mfma_fwd_cols(x.data_ptr(), w2.data_ptr(), scale.data_ptr(), shift.data_ptr(), int(relu), n, h, wd, c, co, stride,
+                                                   y.data_ptr(), None if cols is None else cols.data_ptr(), st), "ocpg_conv3x3_mfma_fwd_cols")
         ctx.has_cols = cols is not None
         if cols is not None:
             ctx.save_for_backward(x, w2, y, scale, cols)
@@ -356,7 +363,12 @@ class Conv3x3MfmaBNAct(Function):
             gx = torch.empty((n, c, h, wd), dtype=y.dtype, device=y.device, memory_format=_CL)
             tok = ctx.premask       # x IS the layer in front's bn + ReLU output: its backward rides in this kernel's epilogue
             mask_ptr, scale_ptr = (x.data_ptr(), tok["scale"].data_ptr()) if tok is not None else (None, None)
-            if DGRAD_OWN_WEIGHT and c % 8 == 0:      # the weight as it lies ([co,3,3,c]): transposing LDS reads, no per-step transposed copy
+            sp = int(L.ocpg_conv3x3_mfma_body_splits(n * h * wd, c, co)) if (BODY_SPLITK and DGRAD_OWN_WEIGHT and c % 8 == 0) else 1
+            if sp > 1:
+                part = torch.empty((sp, n * h * wd, c), dtype=torch.float32, device=y.device)
+                check(L.ocpg_conv3x3_mfma_dgrad_w_splitk(gz.data_ptr(), w2.data_ptr(), mask_ptr, scale_ptr, n, h, wd, c, co, stride, sp, part.data_ptr(),
+                                                         gx.data_ptr(), st), "ocpg_conv3x3_mfma_dgrad_w_splitk")
+            elif DGRAD_OWN_WEIGHT and c % 8 == 0:      # the weight as it lies ([co,3,3,c]): transposing LDS reads, no per-step transposed copy
                 check(L.ocpg_conv3x3_mfma_dgrad_w(gz.data_ptr(), w2.data_ptr(), mask_ptr, scale_ptr, n, h, wd, c, co, stride, gx.data_ptr(), st),
                       "ocpg_conv3x3_mfma_dgrad_w")
             else:

@@ -1190,6 +1190,23 @@ def test_conv3x3_own_weight_gradient_segments_and_ragged_maps(dev, n, c, co, h, 
     _conv3x3_mfma_case(dev, n, c, co, h, w, stride, True, True, True, monkeypatch)
 
 
+@pytest.mark.parametrize("n,c,co,h,w,stride", [(10, 256, 256, 24, 40, 1), (2, 512, 512, 12, 20, 1), (2, 256, 512, 21, 30, 2)])
+def test_conv3x3_body_split_k(dev, n, c, co, h, w, stride, monkeypatch):
+    """The opt-in split-K forward / input gradient of the body's 3x3 convolutions (OCPG_CONV3X3_SPLITK; DESIGN section 5: measured slower
+    in the step): K chains split over the grid, BN + ReLU / mask epilogue in the summing pass -- same results as the un-split kernels."""
+    from ocpg_amd import _lib
+    from ocpg_amd.models.ops.functions import conv_bn_func as f
+    monkeypatch.setattr(f, "BODY_SPLITK", True)
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    assert int(_lib.lib().ocpg_conv3x3_mfma_body_splits(n * ho * wo, co, c)) > 1
+    calls = _lib.census(True)
+    try:
+        _conv3x3_mfma_case(dev, n, c, co, h, w, stride, True, True, True, monkeypatch)
+    finally:
+        _lib.census(False)
+    assert calls.get("ocpg_conv3x3_mfma_fwd_bn_splitk", 0) == 1, calls
+
+
 def _conv3x3_mfma_case(dev, n, c, co, h, w, stride, relu, own_weight, own_wgrad, monkeypatch):
     """csrc/conv3x3_mfma.hip (implicit-GEMM bf16 MFMA 3x3 conv + frozen-BN affine + ReLU in the epilogue, its input-gradient
     twin, im2col + GEMM weight gradient) against F.conv2d in fp32 on the same bf16-rounded operands followed by the affine:
