@@ -1080,31 +1080,68 @@ struct __attribute__((aligned(16))) PItem {
 };
 
 #ifndef EXP_HEAVYP
-#define EXP_HEAVYP 64
+#define EXP_HEAVYP 128
 #endif
 constexpr int kHeavyP = EXP_HEAVYP;        // sample reads from which a patch becomes a whole wave's task
 constexpr int kPatchMax = 512;
+// Light patches in order of their work (round 4, third step).  A wave's eight lane groups walk eight patches in lockstep, so a trip
+// costs the wave what its LONGEST list costs: patches are ranked by work (a 16-bucket counting sort in LDS, heaviest first) and a wave
+// draws eight NEIGHBOURS of that order at a time from a workgroup counter -- groups of a wave see lists of like length and the waves
+// balance themselves (longest tasks first).  0 = the arrival order and the static stride of the first col4.
+#ifndef EXP_TASK_SORT
+#define EXP_TASK_SORT 1
+#endif
+#ifndef EXP_INFLIGHT
+#define EXP_INFLIGHT 3
+#endif
+#ifndef EXP_INFLIGHT_W
+#define EXP_INFLIGHT_W 2
+#endif
+constexpr int kWorkBuckets = 16;
+constexpr int kInFlight = EXP_INFLIGHT;    // items a lane group of a LIGHT patch keeps in flight per trip
 
 // One bin of a patch.  The bin's position (BY, BX) relative to the patch is static, so which accumulators a sample feeds is known at
 // compile time.  Four items in flight per trip.  (Also built and measured, tools/r4_exp9.sh: the three bins of a bin row as ONE contiguous
 // run of items -- they are consecutive in the scan order -- with the bin column carried in the item: 7 instead of 27 dependent LDS round
 // trips per patch, but four selects per item for the column weights: 192 against 177 us.  The sums are bound by instruction issue at
 // low lane efficiency -- lane groups of a wave walk lists of different lengths -- not by LDS latency or bandwidth.)
-template <int BY, int BX, int step>
-__device__ __forceinline__ void patch_bin_sum(const PItem* __restrict__ lst, int n, int first, const float* __restrict__ gsj,
+#ifndef EXP_LEAN_SUM
+#define EXP_LEAN_SUM 1
+#endif
+constexpr int kItemTail = 32;              // zeroed items behind the last list: a trip may read up to 3 * 8 + 7 items past its list's end
+template <int BY, int BX, int step, int NF = 4>
+__device__ __forceinline__ void patch_bin_sum(const PItem* __restrict__ lst, int n, int first, const float* __restrict__ gsj, int zq,
                                               float4 (&acc)[4]) {
-  for (int i = first; i < n; i += 4 * step) {
-    PItem it[4];
+#if EXP_LEAN_SUM
+  // Issue-bound loop (section 4.2c): no per-item index clamp and no per-item weight select.  A trip reads its NF items at constant
+  // offsets from one address -- past the end of a list lie the next lists' items (finite weights, valid rows) and behind the last list
+  // kItemTail zeroed items -- and an item past the end takes the ZERO ROW (zq) instead of its query's row: finite x 0 adds nothing.
+  for (int i = first; i < n; i += NF * step) {
+    const PItem* p = lst + i;
+    PItem it[NF];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) it[u] = lst[min(i + u * step, n - 1)];
-    float4 g[4];
+    for (int u = 0; u < NF; ++u) it[u] = p[u * step];
+    float4 g[NF];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) g[u] = ld4(gsj + it[u].q);
+    for (int u = 0; u < NF; ++u) g[u] = ld4(gsj + (i + u * step < n ? it[u].q : zq));
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NF; ++u) {
+      const float wy[2] = {it[u].wy0, it[u].wy1};
+      const float wx[2] = {1.f - it[u].lx, it[u].lx};
+#else
+  for (int i = first; i < n; i += NF * step) {
+    PItem it[NF];
+#pragma unroll
+    for (int u = 0; u < NF; ++u) it[u] = lst[min(i + u * step, n - 1)];
+    float4 g[NF];
+#pragma unroll
+    for (int u = 0; u < NF; ++u) g[u] = ld4(gsj + it[u].q);
+#pragma unroll
+    for (int u = 0; u < NF; ++u) {
       const bool on = i + u * step < n;
       const float wy[2] = {on ? it[u].wy0 : 0.f, on ? it[u].wy1 : 0.f};
       const float wx[2] = {1.f - it[u].lx, it[u].lx};
+#endif
 #pragma unroll
       for (int cy = 0; cy < 2; ++cy) {
         const int py = BY - 1 + cy;
@@ -1154,13 +1191,15 @@ __global__ __launch_bounds__(NT, 6) void k_scatter_col4(const float* __restrict_
   // workgroup leaves at once
   if (sel != nullptr && sel[kSelCur] != 0) return;
   constexpr int G = 8, D = 32, P = 4, GROUPS = NT / G, NW = NT / 64, BPL = kBins3 / 64;
+  static_assert(kPatchMax <= NT - 64, "a thread of waves 1.. holds at most one patch");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* gs = reinterpret_cast<float*>(smem);                                             // [tmax][D], channel j + G*c at 4*j + c
-  PItem* items = reinterpret_cast<PItem*>(smem + (size_t)geo.tmax * D * sizeof(float));    // [L * tmax * P]
-  int* qg = reinterpret_cast<int*>(items + (size_t)geo.L * geo.tmax * P);                  // [tmax]
+  float* gs = reinterpret_cast<float*>(smem);                                             // [tmax + 1][D], channel j + G*c at 4*j + c; row tmax = zeros
+  PItem* items = reinterpret_cast<PItem*>(smem + (size_t)(geo.tmax + 1) * D * sizeof(float));    // [L * tmax * P + kItemTail]
+  int* qg = reinterpret_cast<int*>(items + (size_t)geo.L * geo.tmax * P + kItemTail);      // [tmax]
   __shared__ int cnt[kBins3], start[kBins3 + 1];
   __shared__ unsigned short task_n[kPatchMax], task_w[kPatchMax];
   __shared__ int boff[kLM + 1], poff[kLM + 1], pcw[kLM], n_narrow, n_wide, n_far;
+  __shared__ int whist[kWorkBuckets], next_task;
   __shared__ unsigned m_pcw[kLM];
   __shared__ TileCtx tc;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1169,7 +1208,9 @@ __global__ __launch_bounds__(NT, 6) void k_scatter_col4(const float* __restrict_
   const int m = bid - bt * M;
   const int b = (int)udiv(bt, geo.ntiles, geo.m_ntiles), tile = bt - b * geo.ntiles;
   for (int i = tid; i < kBins3; i += NT) cnt[i] = 0;
-  if (tid == 0) { n_narrow = 0; n_wide = 0; n_far = 0; }
+  if (tid < kWorkBuckets) whist[tid] = 0;
+  if (tid >= 64 && tid < 64 + D) gs[geo.tmax * D + tid - 64] = 0.f;      // the zero row (patch_bin_sum)
+  if (tid == 0) { n_narrow = 0; n_wide = 0; n_far = 0; next_task = 0; }
   tile_setup(geo, tile, tc, tid);
   const int L = geo.L, NS = L * P, MD = M * D;
   const int T = tc.qbase[L], TL = T * L;
@@ -1254,6 +1295,9 @@ __global__ __launch_bounds__(NT, 6) void k_scatter_col4(const float* __restrict_
     if (lane == 0 && nf) atomicAdd(&n_far, nf);
   }
   __syncthreads();           // gs staged (the direct path below reads it), counts complete
+#if defined(EXP4_CUT) && EXP4_CUT == 1
+  return;                    // timing-only build: loads + binning
+#endif
   {
     // samples outside the window: straight to memory, one sample per wave step, D lanes x 4 B contiguous per corner
     const int lS0 = tc.S0[lv];
@@ -1281,6 +1325,9 @@ __global__ __launch_bounds__(NT, 6) void k_scatter_col4(const float* __restrict_
   }
   // (2) wave 0: list starts of all bins; the other waves: the patch task lists (a patch's work = the counts of its 3 x 3 bins)
   const int npatch = poff[L];
+#if EXP_TASK_SORT
+  int my_pt = -1, my_bucket = 0, my_rank = 0;     // this thread's light patch, its work bucket and its arrival rank inside the bucket
+#endif
   if (wave == 0) {
     int c[BPL], s = 0;
 #pragma unroll
@@ -1316,13 +1363,23 @@ __global__ __launch_bounds__(NT, 6) void k_scatter_col4(const float* __restrict_
       const unsigned long long bn = __ballot(nar), bw = __ballot(wid);
       int basen = 0, basew = 0;
       if (lane == 0) {
+#if !EXP_TASK_SORT
         if (bn) basen = atomicAdd(&n_narrow, __popcll(bn));
+#endif
         if (bw) basew = atomicAdd(&n_wide, __popcll(bw));
       }
       basen = __builtin_amdgcn_readfirstlane(basen);
       basew = __builtin_amdgcn_readfirstlane(basew);
       const unsigned long long below = (1ull << lane) - 1ull;
+#if EXP_TASK_SORT
+      if (nar) {                  // npatch <= kPatchMax <= NT - 64: one trip of this loop, at most one patch per thread
+        my_pt = pt;
+        my_bucket = (kHeavyP - work) * kWorkBuckets / kHeavyP;
+        my_rank = atomicAdd(&whist[my_bucket], 1);
+      }
+#else
       if (nar) task_n[basen + __popcll(bn & below)] = (unsigned short)pt;
+#endif
       if (wid) task_w[basew + __popcll(bw & below)] = (unsigned short)pt;
     }
   }
@@ -1340,18 +1397,41 @@ __global__ __launch_bounds__(NT, 6) void k_scatter_col4(const float* __restrict_
         items[st[p] + slot[p]] = it;
       }
   }
+  if (tid >= NT - kItemTail) {        // zeroed items behind the last list (patch_bin_sum reads past the end of a list)
+    PItem z;
+    z.wy0 = 0.f; z.wy1 = 0.f; z.lx = 0.f; z.q = 0;
+    items[start[kBins3] + tid - (NT - kItemTail)] = z;
+  }
+#if EXP_TASK_SORT
+  {
+    // the light patches into their ranked order: bucket starts from the histogram the barrier above completed
+    int base = 0, all = 0;
+#pragma unroll
+    for (int k = 0; k < kWorkBuckets; ++k) {
+      const int h = whist[k];
+      base += k < my_bucket ? h : 0;
+      all += h;
+    }
+    if (my_pt >= 0) task_n[base + my_rank] = (unsigned short)my_pt;
+    if (tid == 64) n_narrow = all;
+  }
+#endif
   lds_barrier();
+#if defined(EXP4_CUT) && EXP4_CUT == 2
+  return;                    // timing-only build: everything but the sums and the flush
+#endif
   // (4) sums.  Bin (br, bc) of a level's grid holds the samples whose top-left pixel is window pixel (br - 1, bc - 1); patch (pr, pc) owns window
   // pixels rows 2pr .. 2pr+1, columns 2pc .. 2pc+1 and is touched by bins rows 2pr .. 2pr+2, columns 2pc .. 2pc+2.
   const int nw = n_wide, nn = n_narrow;
   const int grp8 = lane >> 3;
   const int odd = grp8 & 1;
   const float* gsj = gs + 4 * j;
+  const int zq = geo.tmax * D;
 #define OCPG_PATCH_BIN(BY, BX)                                                                                     \
   {                                                                                                                \
     const bool ok_ = live_ && 2 * pr + BY <= wh && 2 * pc + BX <= ww;                                              \
     const int bk_ = ok_ ? b0 + BY * (ww + 1) + BX : b0;                                                            \
-    patch_bin_sum<BY, BX, STEP_>(items + start[bk_], ok_ ? cnt[bk_] : 0, first, gsj, acc);                        \
+    patch_bin_sum<BY, BX, STEP_, NF_>(items + start[bk_], ok_ ? cnt[bk_] : 0, first, gsj, zq, acc);               \
   }
 #define OCPG_PATCH_ALL                                                                                             \
   OCPG_PATCH_BIN(0, 0) OCPG_PATCH_BIN(0, 1) OCPG_PATCH_BIN(0, 2) OCPG_PATCH_BIN(1, 0) OCPG_PATCH_BIN(1, 1) OCPG_PATCH_BIN(1, 2)  \
@@ -1370,7 +1450,9 @@ __global__ __launch_bounds__(NT, 6) void k_scatter_col4(const float* __restrict_
     const int first = grp8;
     const bool live_ = true;
 #define STEP_ 8
+#define NF_ EXP_INFLIGHT_W
     OCPG_PATCH_ALL
+#undef NF_
 #undef STEP_
     // reduce-scatter over the 8 lane groups: lane groups g, g ^ 1 end with the total of pixel g / 2 of the patch
     float4 kb[2], kc;
@@ -1392,8 +1474,18 @@ __global__ __launch_bounds__(NT, 6) void k_scatter_col4(const float* __restrict_
     const bool live = !odd && prow < wh && pcol < ww && (kc.x != 0.f || kc.y != 0.f || kc.z != 0.f || kc.w != 0.f);
     pair_flush(kc, live ? tc.S0[l] + (tc.wy0[l] + prow) * tc.W[l] + tc.wx0[l] + pcol : -1, odd, j, gvb, MD);
   }
+#if EXP_TASK_SORT
+  for (;;) {                                                  // light patches: a wave draws eight neighbours of the ranked order
+    int kbase = 0;
+    if (lane == 0) kbase = atomicAdd(&next_task, 8);
+    kbase = __builtin_amdgcn_readfirstlane(kbase);
+    if (kbase >= nn) break;
+    const int kk = kbase + grp8;
+    const bool valid = kk < nn;
+#else
   for (int kk = tid / G; kk - odd < nn; kk += GROUPS) {       // light patches: one lane group each (kk - odd: pairs of groups leave the loop together)
     const bool valid = kk < nn;
+#endif
     const int pt = valid ? task_n[kk] : 0;
     int l = 0;
 #pragma unroll
@@ -1407,7 +1499,9 @@ __global__ __launch_bounds__(NT, 6) void k_scatter_col4(const float* __restrict_
     const int first = 0;
     const bool live_ = valid;
 #define STEP_ 1
+#define NF_ kInFlight
     OCPG_PATCH_ALL
+#undef NF_
 #undef STEP_
     const int pbase = tc.S0[l] + (tc.wy0[l] + 2 * pr) * tc.W[l] + tc.wx0[l] + 2 * pc, lw = tc.W[l];
 #pragma unroll
@@ -1426,7 +1520,7 @@ __global__ __launch_bounds__(NT, 6) void k_scatter_col4(const float* __restrict_
 }
 
 inline size_t scatter4_lds(const ColGeom& g) {
-  return (size_t)g.tmax * 32 * sizeof(float) + (size_t)g.L * g.tmax * 4 * sizeof(PItem) + (size_t)g.tmax * sizeof(int);
+  return (size_t)(g.tmax + 1) * 32 * sizeof(float) + ((size_t)g.L * g.tmax * 4 + kItemTail) * sizeof(PItem) + (size_t)g.tmax * sizeof(int);
 }
 
 // the patch kernel: D = 32, P = 4, 768 threads (a thread per (query, level)), bin grids and patches within the static tables

@@ -44,6 +44,20 @@ def ring_loc(noise, outliers, seed=0):
     return loc.contiguous()
 
 
+_COLD = None
+
+
+def cold():
+    """GV_COLD=1: 1 GiB written between calls, so that no operand of the timed call is left in the L2s / the 256 MB memory-side cache
+    (inside the training step the kernel starts on cold operands; back to back it does not)."""
+    global _COLD
+    if os.environ.get("GV_COLD") != "1":
+        return
+    if _COLD is None:
+        _COLD = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    _COLD.fill_(1.0)
+
+
 def run(loc, attn, go, gv, iters):
     rc = lib().ocpg_msda_bwd_value_f32(loc.data_ptr(), attn.data_ptr(), go.data_ptr(), N, S, M, D, L, S, P, gv.data_ptr(),
                                        ctypes.c_void_p(shapes.data_ptr()), stream_ptr())
@@ -52,6 +66,7 @@ def run(loc, attn, go, gv, iters):
     e = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
     for a, b in e:
         gv.zero_()
+        cold()
         a.record()
         lib().ocpg_msda_bwd_value_f32(loc.data_ptr(), attn.data_ptr(), go.data_ptr(), N, S, M, D, L, S, P, gv.data_ptr(),
                                       ctypes.c_void_p(shapes.data_ptr()), stream_ptr())
@@ -97,6 +112,7 @@ for mode, (noise, outl) in (("ring", (0.0, 0.0)), ("ring+n", (1.5, 0.02)), ("tra
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(int(os.environ.get("ITERS", "30")))]
         for a, b in ev:
             gv.zero_()
+            cold()
             a.record()
             call()
             b.record()
