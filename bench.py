@@ -348,41 +348,79 @@ class GraphStep:
 
 
 class SegmentedGraphStep(GraphStep):
-    """The captured step cut into THREE graphs at two points of the ResNet backward, so that the gradient all-reduce of one part
+    """The captured step cut into THREE graphs at activations of the backbone's backward, so that the gradient all-reduce of one part
     overlaps the backward of the next (main.py:62's DistributedDataParallel overlaps bucket by bucket; a single captured graph
     cannot: its gradients only exist when the replay ends):
         G1  forward + criterion + backward of everything behind the backbone      -> all-reduce bucket 0 (neck, transformer, heads)
-        G2  backward of layer4 and the later half of layer3                        -> all-reduce bucket 1   | while G2 / G3 run
-        G3  backward of the first half of layer3 and of layer2                     -> all-reduce bucket 2   (the only exposed one)
-    Each part's autocast parameters have their OWN fused-cast node (amp_cache.set_groups), so their fp32 gradients are born as views
-    of ONE flat buffer per part: the buckets are those buffers themselves (no flatten / copy-back), plus one small flattened
-    remainder for parameters outside the cast (fp32 islands).  ResNet backbones, no GradScaler; anything else keeps GraphStep."""
+        G2  backward of the late backbone                                          -> all-reduce bucket 1   | while G2 / G3 run
+        G3  backward of the early backbone                                         -> all-reduce bucket 2   (the only exposed one)
+    ResNet (configs #1-#3): G2 = layer4 + the later half of layer3, G3 = the first half of layer3 + layer2.  Video-Swin (configs #4 / #5):
+    G2 = stages 3 and 2 with the patch mergings in front of them, G3 = stages 1 and 0 + the patch embedding (stage outputs feed the
+    neck AND the next stage, as the ResNet layers do).  Each part's autocast parameters have their OWN fused-cast node
+    (amp_cache.set_groups), so their fp32 gradients are born as views of ONE flat buffer per part: the buckets are those buffers
+    themselves (no flatten / copy-back), plus one small flattened remainder for parameters outside the cast (fp32 islands).  fp16: the
+    SCALED loss is differentiated (engine.py:98-104); the buckets carry scaled gradients and ClipAdamW unscales after the waits."""
 
     SPLIT = 10          # layer3 blocks [0, SPLIT) belong to G3, [SPLIT, 23) to G2 (ResNet-101: ~12 M / ~29 M backbone parameters)
 
     @staticmethod
-    def supported(model, amp_dtype):
+    def _kind(model):
         body = getattr(model.backbone[0], "body", None)
-        return amp_dtype == torch.bfloat16 and body is not None and all(hasattr(body, f"layer{i}") for i in (2, 3, 4)) and len(body.layer3) >= 2
+        if body is None:
+            return None
+        if all(hasattr(body, f"layer{i}") for i in (2, 3, 4)) and len(body.layer3) >= 2:
+            return "resnet"
+        if hasattr(body, "layers") and hasattr(body, "downsamples") and hasattr(body, "patch_embed") and len(body.layers) in (3, 4):
+            return "swin"
+        return None
 
-    def __init__(self, model, criterion, optimizer, make_samples, text, targets, args, amp_dtype, world):
-        from ocpg_amd.models import amp_cache
+    @staticmethod
+    def supported(model, amp_dtype):
+        return amp_dtype in (torch.bfloat16, torch.float16) and SegmentedGraphStep._kind(model) is not None
+
+    @staticmethod
+    def plan(model):
+        """-> (group_of, cuts, hops): group_of(parameter name) in 0..4 (0 = behind the backbone), cuts = [(key, module)] in forward order
+        (the module's output becomes a detached leaf in the captured forward), hops = per later graph [(from key, group, to key | None)]:
+        `grad(orig[from], P[group] + [leaf[to]], grad_outputs = what has arrived at leaf[from])`."""
         body = model.backbone[0].body
-        k = min(self.SPLIT, len(body.layer3) - 1)
+        if SegmentedGraphStep._kind(model) == "resnet":
+            k = min(SegmentedGraphStep.SPLIT, len(body.layer3) - 1)
 
-        def group_of(n):     # 0 behind the backbone | 1 layer4 | 2 layer3[k:] | 3 layer3[:k] | 4 layer2 (and the frozen stem / layer1)
+            def group_of(n):     # 0 behind the backbone | 1 layer4 | 2 layer3[k:] | 3 layer3[:k] | 4 layer2 (and the frozen stem / layer1)
+                if not n.startswith("backbone.0.body."):
+                    return 0
+                q = n.split(".")
+                if q[3] == "layer4":
+                    return 1
+                if q[3] == "layer3":
+                    return 2 if int(q[4]) >= k else 3
+                return 4
+            cuts = (("f8", body.layer2), ("mid", body.layer3[k - 1]), ("f16", body.layer3), ("f32", body.layer4))
+            hops = ([("f32", 1, "f16"), ("f16", 2, "mid")], [("mid", 3, "f8"), ("f8", 4, None)])
+            return group_of, cuts, hops
+        n_st = len(body.layers)          # 4 (3 when the last stage is not built): stage i owns the patch merging in front of it
+        # (downsamples[i - 1]), stage 0 the patch embedding; the two LAST stages go to G2, the earlier ones to G3
+        group = {n_st - 1: 1, n_st - 2: 2, n_st - 3: 3}
+        if n_st == 4:
+            group[0] = 4
+
+        def group_of(n):     # 0 behind the backbone | 1 last stage | 2 the stage before it | 3, 4 the stages before that
             if not n.startswith("backbone.0.body."):
                 return 0
             q = n.split(".")
-            if q[3] == "layer4":
-                return 1
-            if q[3] == "layer3":
-                return 2 if int(q[4]) >= k else 3
-            return 4
-        self.group_of = group_of
-        amp_cache.set_groups(model, group_of)       # one fused-cast node (one flat gradient buffer) per part: see _capture
-        self.cut_modules = (("f8", body.layer2), ("mid", body.layer3[k - 1]), ("f16", body.layer3), ("f32", body.layer4))
-        self.split_k = k
+            st = int(q[4]) if q[3] == "layers" else int(q[4]) + 1 if q[3] == "downsamples" else 0
+            return group[st]
+        cuts = tuple((f"s{i}", body.layers[i]) for i in range(n_st))
+        hops = ([(f"s{n_st - 1}", 1, f"s{n_st - 2}"), (f"s{n_st - 2}", 2, f"s{n_st - 3}")],
+                [(f"s{i}", group[i], f"s{i - 1}" if i > 0 else None) for i in range(n_st - 3, -1, -1)])
+        return group_of, cuts, hops
+
+    def __init__(self, model, criterion, optimizer, make_samples, text, targets, args, amp_dtype, world):
+        from ocpg_amd.models import amp_cache
+        self.kind = self._kind(model)
+        self.group_of, self.cut_modules, self.hops = self.plan(model)
+        amp_cache.set_groups(model, self.group_of)       # one fused-cast node (one flat gradient buffer) per part: see _capture
         super().__init__(model, criterion, optimizer, make_samples, text, targets, args, amp_dtype, world)
 
     def _capture(self, side, text, targets):
@@ -390,10 +428,54 @@ class SegmentedGraphStep(GraphStep):
         model, criterion = self.model, self.criterion
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         P = [[p for n, p in named if self.group_of(n) == i] for i in range(5)]
-        # The backward is CUT at four activations: in the captured forward each of them is replaced by a detached leaf (the module's
-        # forward hook returns it), so the sub-graphs on either side are disjoint and `autograd.grad` over one of them neither needs
-        # nor runs the other (without the cut, d loss / d f8 is a TOTAL derivative: autograd would run layer3 and layer4 to deliver it).
-        orig, leaf = {}, {}
+        mode = "thread_local" if self.world > 1 else "global"
+        self.graphs = [torch.cuda.CUDAGraph(keep_graph=True) for _ in range(3)]
+        st = self.static
+        pool = []
+
+        def part(i):        # the capture of graph i (graphs 1, 2 share graph 0's pool: gradients handed from one to the next)
+            if i == 0:
+                return torch.cuda.graph(self.graphs[0], stream=side, capture_error_mode=mode)
+            if not pool:
+                pool.append(self.graphs[0].pool())
+            return torch.cuda.graph(self.graphs[i], stream=side, pool=pool[0], capture_error_mode=mode)
+
+        def forward_loss():
+            with torch.autocast(device_type=self.x.device.type, dtype=self.amp_dtype):
+                out = model(NestedTensor(self.x.clone(), self._mask()), text, targets)
+                out["num_boxes"] = self.num_boxes
+                loss_dict, *_ = criterion(out, targets)
+                loss = criterion.weighted_sum(loss_dict)
+            st.update(out=out, loss_dict=loss_dict, loss=loss)
+            return self.scaler.scale(loss) if self.scaler is not None else loss
+        with self.rng:
+            glists, groups, keep = self.segmented_backward(forward_loss, P, self.cut_modules, self.hops, part, last=self.rng.advance)
+        st.update(keep)
+        st["g0"], st["g1"], st["g2"] = glists
+        loss = st["loss"]
+        seg_params = [[p for k in gr for p in P[k]] for gr in groups]
+        assert sum(len(x_) for x_ in seg_params) == len(named), "a trainable parameter belongs to no segment"
+        self.rng.finalize()
+        for i, gr in enumerate(self.graphs):
+            self._repair_and_instantiate(gr, stats=(i == 0))
+        self.loss = loss.detach()
+        for ps, gs in zip(seg_params, (st["g0"], st["g1"], st["g2"])):
+            for p_, g_ in zip(ps, gs):
+                assert g_ is not None, "a trainable parameter received no gradient"
+                p_.grad = g_            # static tensors of the graphs' pool: every replay refills them
+        self.buckets = self.build_buckets((st["g0"], st["g1"], st["g2"]), self.x.device)
+        self.bucket_bytes = [4 * (sum(b.numel() for b in bk["dense"]) + (bk["small"].numel() if bk["small"] is not None else 0)) for bk in self.buckets]
+
+    @staticmethod
+    def segmented_backward(forward_loss, P, cut_modules, hops, part, last=None):
+        """The three parts of the step (capture-independent: `part(i)` is the context the i-th part runs in -- a graph capture in
+        _capture, a null context in the CPU test).  The backward is CUT at the plan's activations: in the forward each of them is
+        replaced by a detached leaf (the module's forward hook returns it), so the sub-graphs on either side are disjoint and
+        `autograd.grad` over one of them neither needs nor runs the other (without the cut, d loss / d f8 is a TOTAL derivative:
+        autograd would run layer3 and layer4 to deliver it).  Every hop has its own parameter group (its own fused-cast node).
+        -> ([g0, g1, g2] gradient lists, [groups of P behind each list], tensors to keep alive)."""
+        orig, leaf, arrived = {}, {}, {}        # arrived: key -> gradient that has reached that leaf so far (None: nothing yet)
+        grad = torch.autograd.grad
 
         def cut(key):
             def hook(mod, inp, out):
@@ -401,44 +483,39 @@ class SegmentedGraphStep(GraphStep):
                 leaf[key] = out.detach().requires_grad_(True)
                 return leaf[key]
             return hook
-        self.hooks = [m.register_forward_hook(cut(key)) for key, m in self.cut_modules]
-        mode = "thread_local" if self.world > 1 else "global"
-        self.graphs = [torch.cuda.CUDAGraph(keep_graph=True) for _ in range(3)]
-        st = self.static
-        grad = torch.autograd.grad
-        with self.rng:
-            with torch.cuda.graph(self.graphs[0], stream=side, capture_error_mode=mode):
-                with torch.autocast(device_type=self.x.device.type, dtype=self.amp_dtype):
-                    out = model(NestedTensor(self.x.clone(), self._mask()), text, targets)
-                    out["num_boxes"] = self.num_boxes
-                    loss_dict, *_ = criterion(out, targets)
-                    loss = criterion.weighted_sum(loss_dict)
-                g = grad(loss, P[0] + [leaf["f8"], leaf["f16"], leaf["f32"]])
-                st["g0"], (g8, g16, g32) = list(g[:len(P[0])]), g[len(P[0]):]
-                st.update(out=out, loss_dict=loss_dict, loss=loss, orig=orig, leaf=leaf, gb=(g8, g16, g32))
-            pool = self.graphs[0].pool()
-            with torch.cuda.graph(self.graphs[1], stream=side, pool=pool, capture_error_mode=mode):
-                g = grad(orig["f32"], P[1] + [leaf["f16"]], grad_outputs=g32)                     # layer4
-                g_l4, g16_l4 = list(g[:-1]), g[-1]
-                g = grad(orig["f16"], P[2] + [leaf["mid"]], grad_outputs=g16 + g16_l4)            # layer3[k:]  (f16 feeds the neck AND layer4)
-                st["g1"], gmid = g_l4 + list(g[:-1]), g[-1]
-            with torch.cuda.graph(self.graphs[2], stream=side, pool=pool, capture_error_mode=mode):
-                g = grad(orig["mid"], P[3] + [leaf["f8"]], grad_outputs=gmid)                     # layer3[:k]
-                g_l3a, g8_l3 = list(g[:-1]), g[-1]
-                st["g2"] = g_l3a + list(grad(orig["f8"], P[4], grad_outputs=g8 + g8_l3))           # layer2  (f8 feeds the neck AND layer3)
-                self.rng.advance()      # last node of the step: the next replay draws fresh dropout masks
-        seg_params = [P[0], P[1] + P[2], P[3] + P[4]]
-        self.rng.finalize()
-        for h in self.hooks:
-            h.remove()
-        for i, gr in enumerate(self.graphs):
-            self._repair_and_instantiate(gr, stats=(i == 0))
-        self.loss = loss.detach()
-        for ps, gs in zip(seg_params, (st["g0"], st["g1"], st["g2"])):
-            for p_, g_ in zip(ps, gs):
-                p_.grad = g_            # static tensors of the graphs' pool: every replay refills them
-        self.buckets = self.build_buckets((st["g0"], st["g1"], st["g2"]), self.x.device)
-        self.bucket_bytes = [4 * (sum(b.numel() for b in bk["dense"]) + (bk["small"].numel() if bk["small"] is not None else 0)) for bk in self.buckets]
+        hooks = [m.register_forward_hook(cut(key)) for key, m in cut_modules]
+        keys = [k for k, _ in cut_modules]
+
+        def walk(hs):
+            got = {}
+            for src, g_id, dst in hs:
+                wrt = P[g_id] + ([leaf[dst]] if dst is not None else [])
+                g = grad(orig[src], wrt, grad_outputs=arrived[src], allow_unused=True)
+                got[g_id] = list(g[:len(P[g_id])])
+                if dst is not None:
+                    arrived[dst] = g[-1] if arrived.get(dst) is None else arrived[dst] + g[-1]
+            return got
+        try:
+            with part(0):
+                loss = forward_loss()
+                g = grad(loss, P[0] + [leaf[k] for k in keys], allow_unused=True)
+                g0 = list(g[:len(P[0])])
+                for k, gk in zip(keys, g[len(P[0]):]):
+                    arrived[k] = gk
+                first = dict(arrived)
+            lists, groups = [g0], [[0]]
+            for i, hs in enumerate(hops):
+                with part(i + 1):
+                    got = walk(hs)
+                    order = sorted(got)
+                    lists.append([g_ for k in order for g_ in got[k]])
+                    groups.append(order)
+                    if i == len(hops) - 1 and last is not None:
+                        last()          # last node of the step (the captured step: the next replay draws fresh dropout masks)
+        finally:
+            for h in hooks:
+                h.remove()
+        return lists, groups, {"orig": orig, "leaf": leaf, "gb": first, "arrived": arrived}
 
     @staticmethod
     def build_buckets(grad_lists, device):
