@@ -153,6 +153,8 @@ class GraphStep:
     loop: ~9 500 kernels per step).  Outside the graph, per step: copy the batch into the static input buffers, the
     criterion's num_boxes all-reduce, (N>1) one flat gradient all-reduce over RCCL, grad clip, AdamW."""
 
+    INIT_SCALE = None       # fp16: the GradScaler's initial scale (None = torch's 65536; tests compare gradients at a scale that does not overflow)
+
     def __init__(self, model, criterion, optimizer, make_samples, text, targets, args, amp_dtype, world):
         from ocpg_amd.util.misc import NestedTensor
         self.model, self.criterion, self.optimizer, self.args, self.world = model, criterion, optimizer, args, world
@@ -160,7 +162,8 @@ class GraphStep:
         self.fence = os.environ.get("OCPG_GRAPH_FENCE") == "1"       # diagnostic: host syncs around every replay
         # fp16: the reference's GradScaler path (engine.py:98-104).  The scale is a device scalar, so `scale(loss).backward()` is
         # captured; unscale_ / clip / step (with its inf check) / update stay eager after the replay
-        self.scaler = torch.amp.GradScaler("cuda") if amp_dtype == torch.float16 else None
+        self.scaler = (torch.amp.GradScaler("cuda", **({"init_scale": self.INIT_SCALE} if self.INIT_SCALE else {}))
+                       if amp_dtype == torch.float16 else None)
         # captions (config #5): tokenisation uploads host tensors, which a capture cannot contain.  The FROZEN text backbone therefore
         # runs eagerly before every replay (same work per step as the eager path, `freeze_text_encoder` as in every launch script) and
         # hands its outputs to the captured step through static buffers; the trainable resizers stay inside the graph.
