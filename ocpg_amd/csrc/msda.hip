@@ -1192,7 +1192,7 @@ int ocpg_msda_bwd_value_sel_f32(const float* loc, const float* attn, const float
         ocpg_tile::tile_supported(shapes_host, N, L, S, M, P, D)) {
       if (ocpg_col::bwd_scatter_col(loc, attn, grad_out, N, S, M, D, P, cg, grad_value, st, sel_state, to_tile) != 2) return -2001;
       if (!ocpg_tile::bwd_value_tile(loc, attn, grad_out, shapes_host, N, S, M, D, L, P, grad_value, st, sel_state, to_col)) return -2002;
-      ocpg_col::select_commit(sel_state, st);
+      ocpg_col::select_commit(sel_state, to_tile, to_col, st);
       return launch_status();
     }
   }

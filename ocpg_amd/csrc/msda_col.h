@@ -40,33 +40,23 @@ bool scatter_supported(const ColGeom& g, int D, int P);
 // Every call launches both paths' kernels; the workgroups of the path that is not current leave at once (a few microseconds).  The
 // active path counts the samples that miss its locality assumption and proposes the path of the NEXT call (hysteresis: two thresholds);
 // a one-thread kernel at the end of the launch sequence commits the proposal.  No host round trip: the same launches replay inside a HIP graph.
-enum { kSelFar = 0, kSelTotal = 1, kSelTicketA = 2, kSelCur = 3, kSelNext = 4, kSelTicketB = 5, kSelLastFar = 6, kSelLastTotal = 7 };
+enum { kSelFar = 0, kSelTotal = 1, kSelUnusedA = 2, kSelCur = 3, kSelNext = 4, kSelUnusedB = 5, kSelLastFar = 6, kSelLastTotal = 7 };   // [0..1]: the packed 64-bit report word
 
-// The active path's (sampled) workgroups add (far samples, samples) and draw a ticket; the last of them turns the totals into the path
-// proposed for the NEXT call.  The proposal becomes current in a one-thread kernel launched after every kernel of this call (select_commit):
-// no kernel of a call may see the state change under it.
-__device__ __forceinline__ void sel_publish(int* sel, int ticket_slot, int far, int total, int nblocks, int pct, int path_if_over,
-                                            int path_if_under) {
-  if (far) atomicAdd(sel + kSelFar, far);
-  if (total) atomicAdd(sel + kSelTotal, total);
-  __threadfence();
-  if (atomicAdd(sel + ticket_slot, 1) == nblocks - 1) {
-    __threadfence();
-    const int f = atomicAdd(sel + kSelFar, 0), t = atomicAdd(sel + kSelTotal, 0);
-    if (t > 0) {
-      sel[kSelNext] = (long long)f * 100 > (long long)pct * t ? path_if_over : path_if_under;
-      sel[kSelLastFar] = f;
-      sel[kSelLastTotal] = t;
-    }
-    sel[kSelFar] = 0;
-    sel[kSelTotal] = 0;
-    sel[ticket_slot] = 0;
-    __threadfence();
-  }
+// The active path's (sampled) workgroups report (far samples, samples) with ONE fire-and-forget 64-bit atomic on the packed word at
+// sel[kSelFar .. kSelTotal] (bits 0..31 samples, 32..63 far samples); nothing comes back, nobody waits.  The one-thread kernel launched
+// after every kernel of the call (select_commit) reads the word -- complete at the kernel boundary --, turns it into the path of the
+// NEXT call (two thresholds: hysteresis), makes it current and clears the word: no kernel of a call sees the state change under it.
+// (Round 4, first half: two adds, a fence, a ticket, a fence and two read-backs per reporting workgroup at the END of the kernel -- on
+// cold operands the reporting workgroups waited for their returning atomics behind the flush traffic and the launch ended 27 us later:
+// 184-188 vs 158 us, tools/ab_gv_sel.sh.  A returning atomic issued early and consumed late kept two registers alive through the sums
+// of a kernel at its 80-register cap: 172 vs 160 us.)
+__device__ __forceinline__ void sel_report(int* sel, int far, int total) {
+  atomicAdd(reinterpret_cast<unsigned long long*>(sel + kSelFar), ((unsigned long long)(unsigned)far << 32) | (unsigned long long)(unsigned)total);
 }
 
-// last launch of a call that passed `sel`: current path = proposed path
-void select_commit(int* sel, hipStream_t st);
+// last launch of a call that passed `sel`: this call's reports -> the next call's path (the column family moves to the tiled one above
+// to_tile_pct percent far samples, the tiled family back below to_col_pct), which becomes current
+void select_commit(int* sel, int to_tile_pct, int to_col_pct, hipStream_t st);
 
 // true: the one-pass patch kernel (the only column kernel that takes part in the selection) serves this geometry
 bool select_supported(const ColGeom& g, int D, int P);

@@ -1189,7 +1189,15 @@ __global__ __launch_bounds__(NT, 6) void k_scatter_col4(const float* __restrict_
                                                          float* __restrict__ gvalue, int* __restrict__ sel, int to_tile_pct) {
   // path selection (msda_col.h): this kernel is path 0; when the call site's state says the output-tiled kernels serve this call, every
   // workgroup leaves at once
+#ifndef EXP_SEL_CHECK
+#define EXP_SEL_CHECK 1
+#endif
+#ifndef EXP_SEL_STAT
+#define EXP_SEL_STAT 1
+#endif
+#if EXP_SEL_CHECK
   if (sel != nullptr && sel[kSelCur] != 0) return;
+#endif
   constexpr int G = 8, D = 32, P = 4, GROUPS = NT / G, NW = NT / 64, BPL = kBins3 / 64;
   static_assert(kPatchMax <= NT - 64, "a thread of waves 1.. holds at most one patch");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1288,13 +1296,15 @@ __global__ __launch_bounds__(NT, 6) void k_scatter_col4(const float* __restrict_
 #pragma unroll
   for (int p = 0; p < 4; ++p)
     if (bin[p] >= 0) slot[p] = atomicAdd(&cnt[bin[p]], 1);
-  if (sel != nullptr) {      // this call's share of samples outside the windows: what the NEXT call at this site is dispatched on
+  if (EXP_SEL_STAT == 1 ? sel != nullptr : EXP_SEL_STAT == 2 ? (sel != nullptr && (blockIdx.x & 15) == 0) : false) {      // this call's share of samples outside the windows: what the NEXT call at this site is dispatched on
     int nf = 0;
 #pragma unroll
     for (int p = 0; p < 4; ++p) nf += __popcll(__ballot(bin[p] < -1));
     if (lane == 0 && nf) atomicAdd(&n_far, nf);
   }
   __syncthreads();           // gs staged (the direct path below reads it), counts complete
+  // the call site's statistics: every 16th workgroup reports (400 k samples estimate a share well enough) with one fire-and-forget atomic
+  if (EXP_SEL_STAT != 0 && sel != nullptr && tid == NT - 1 && (bid & 15) == 0) sel_report(sel, n_far, TL * 4);
 #if defined(EXP4_CUT) && EXP4_CUT == 1
   return;                    // timing-only build: loads + binning
 #endif
@@ -1361,6 +1371,7 @@ __global__ __launch_bounds__(NT, 6) void k_scatter_col4(const float* __restrict_
       }
       const bool nar = work > 0 && work <= kHeavyP, wid = work > kHeavyP;
       const unsigned long long bn = __ballot(nar), bw = __ballot(wid);
+      (void)bn;
       int basen = 0, basew = 0;
       if (lane == 0) {
 #if !EXP_TASK_SORT
@@ -1512,11 +1523,7 @@ __global__ __launch_bounds__(NT, 6) void k_scatter_col4(const float* __restrict_
   }
 #undef OCPG_PATCH_ALL
 #undef OCPG_PATCH_BIN
-  // the call site's statistics, as the LAST thing this workgroup does (the ticket is a returning global atomic: microseconds -- in front of
-  // a barrier it held up all 12 waves: +50 us per launch measured)
-  // Every 16th workgroup reports (2 400 returning atomics on one word are ~27 us of serialised traffic; 150 are not, and 400 k samples
-  // estimate a share well enough).
-  if (sel != nullptr && tid == 0 && (bid & 15) == 0) sel_publish(sel, kSelTicketA, n_far, TL * 4, ((int)gridDim.x + 15) >> 4, to_tile_pct, 1, 0);
+
 }
 
 inline size_t scatter4_lds(const ColGeom& g) {
@@ -1651,11 +1658,22 @@ int fwd_col(const float* value, const float* loc, const float* attn, int N, int 
   return 1;
 }
 
-__global__ void k_sel_commit(int* sel) {
-  if (threadIdx.x == 0) sel[kSelCur] = sel[kSelNext];
+__global__ void k_sel_commit(int* sel, int to_tile_pct, int to_col_pct) {
+  if (threadIdx.x != 0) return;
+  unsigned long long* word = reinterpret_cast<unsigned long long*>(sel + kSelFar);
+  const unsigned long long w = *word;
+  const long long f = (long long)(w >> 32), t = (long long)(w & 0xffffffffull);
+  if (t > 0) {        // (a call whose active family reported nothing keeps the path)
+    const int cur = sel[kSelCur];
+    sel[kSelNext] = cur == 0 ? (f * 100 > (long long)to_tile_pct * t ? 1 : 0) : (f * 100 > (long long)to_col_pct * t ? 1 : 0);
+    sel[kSelLastFar] = (int)f;
+    sel[kSelLastTotal] = (int)t;
+    *word = 0ull;
+  }
+  sel[kSelCur] = sel[kSelNext];
 }
 
-void select_commit(int* sel, hipStream_t st) { k_sel_commit<<<1, 64, 0, st>>>(sel); }
+void select_commit(int* sel, int to_tile_pct, int to_col_pct, hipStream_t st) { k_sel_commit<<<1, 64, 0, st>>>(sel, to_tile_pct, to_col_pct); }
 
 bool select_supported(const ColGeom& g, int D, int P) {
   const char* e = std::getenv("OCPG_MSDA_COL_LP");

@@ -20,7 +20,7 @@
 // sampling locations.  A round = 256 candidate queries x the 4 points of one level: 4 barriers per round with 16 corner
 // contributions per thread between them (round 2: 5 barriers per level with one sample per thread).
 #include "msda_tile.h"
-#include "msda_col.h"       // path-selection state (SelState slots, sel_publish)
+#include "msda_col.h"       // path-selection state (SelState slots, sel_report / sel_decide)
 
 #include <algorithm>
 #include <cstdlib>
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(NT, NPX <= 10 ? 3 : 1) void k_gv_coarse(const float
     for (int o = 32; o > 0; o >>= 1) { far_seen += __shfl_xor(far_seen, o, 64); fine_seen += __shfl_xor(fine_seen, o, 64); }
     if (lane == 0) { atomicAdd(&sel_far, far_seen); atomicAdd(&sel_seen, fine_seen); }
     __syncthreads();
-    if (tid == 0) ocpg_col::sel_publish(sel, ocpg_col::kSelTicketB, sel_far, sel_seen, ((int)gridDim.x + 7) >> 3, to_col_pct, 1, 0);
+    if (tid == 0) ocpg_col::sel_report(sel, sel_far, sel_seen);
   }
   STAMP(15);
   STAMP_FLUSH(8);
