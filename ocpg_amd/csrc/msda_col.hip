@@ -1314,6 +1314,9 @@ __global__ __launch_bounds__(NT, 6) void k_scatter_col4(const float* __restrict_
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       unsigned long long bal = __ballot(bin[p] < -1);
+#ifdef EXP_NO_FAR
+      bal = 0;               // timing-only build: samples outside the windows are dropped
+#endif
       while (bal) {
         const int src = __ffsll((long long)bal) - 1;
         bal &= bal - 1;
