@@ -1059,12 +1059,18 @@ def main():
                 # the ring row once more with the calls issued back to back (the extra eager steps are host-bound: the four launches of
                 # the selecting entry point -- active kernel, two idle ones, commit -- show their launch gaps there, a graph replay does not)
                 rk = time_msda_kernels(nfr, device).get("bwd_enc_value")
-                if rk and rk["n"]:
-                    us0 = rk["ms"] / rk["n"] * 1e3
-                    ring.update(launch_us_in_eager_steps=ring["launch_us"], launch_us=us0, achieved=dom["algorithmic_bytes"] / us0 / 1e3,
-                                frac=dom["algorithmic_bytes"] / us0 / 1e3 / HBM_PEAK_GBS, launches_timed=rk["n"],
-                                timed_in="this process, after the timed steps: the entry point on the model's initial ring offsets, calls back to back "
-                                         "(HIP events on the launch stream); launch_us_in_eager_steps = the same call inside the extra eager steps")
+                # ... and the KERNEL ALONE: the plain entry point (ocpg_msda_bwd_value_f32) launches k_scatter_col4 and nothing else -- the
+                # duration rocprofv3's per-kernel average of the same command has to agree with (profiles/r04_bench_rocprofv3_kernel_stats.csv)
+                r1 = time_msda_kernels(nfr, device, select=False).get("bwd_enc_value")
+                if rk and rk["n"] and r1 and r1["n"]:
+                    us0, us1 = rk["ms"] / rk["n"] * 1e3, r1["ms"] / r1["n"] * 1e3
+                    ring.update(kernel="k_scatter_col4 -- " + what, launch_us_in_eager_steps=ring["launch_us"], entry_point_us=us0, launch_us=us1,
+                                achieved=dom["algorithmic_bytes"] / us1 / 1e3, frac=dom["algorithmic_bytes"] / us1 / 1e3 / HBM_PEAK_GBS,
+                                launches_timed=r1["n"],
+                                timed_in="this process, after the timed steps, calls back to back on the model's initial ring offsets (HIP events on "
+                                         "the launch stream): launch_us = the kernel alone (ocpg_msda_bwd_value_f32: one launch), entry_point_us = the "
+                                         "selecting entry point the step calls (this kernel + two idle launches of the tiled family + the one-thread "
+                                         "commit), launch_us_in_eager_steps = that entry point inside the extra eager steps")
                 # `roofline` stays the kernel the timed steps launch (the contract's definition); next to it the same entry point
                 # on perturbed ("trained-like") offsets -- +3 px gaussian noise, 5 % of the samples anywhere in the map -- through the
                 # per-call selection, which moves such a call site to the output-tiled kernels
