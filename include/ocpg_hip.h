@@ -80,7 +80,8 @@ int ocpg_msda_bwd_locattn_f32(const float* value, const int64_t* shapes, const i
 /* ocpg_msda_bwd_value_f32 with PER-CALL PATH SELECTION (round 4; replaces the same reference kernel, cuh:301-403 via cu:83-152, for
  * grad_value).  Two kernel families serve the self-attention shape: the query-owned column scatter (fastest while the offsets stay
  * within ~5 pixels of the query, as at initialisation) and the output-tiled kernels (no halo atomics: ahead once training has spread
- * the offsets).  sel_state: 8 ints of device memory owned by the CALL SITE (one per MSDeformAttn module), zero-filled once and passed
+ * the offsets).  sel_state: 8 ints of device memory (8-byte aligned: slots 0 / 1 are one 64-bit word the reporting workgroups add to)
+ * owned by the CALL SITE (one per MSDeformAttn module), zero-filled once and passed
  * to every call; the kernels keep in it the share of samples that missed the active path's locality assumption and the path the next
  * call takes (0 = column, 1 = tiled; slots 6 / 7: far and total samples of the last call, for diagnostics).  Both families are launched
  * on every call and the inactive one's workgroups return at once, so the choice needs no host round trip and survives HIP-graph replay.
