@@ -1080,7 +1080,7 @@ struct __attribute__((aligned(16))) PItem {
 };
 
 #ifndef EXP_HEAVYP
-#define EXP_HEAVYP 128
+#define EXP_HEAVYP 64
 #endif
 constexpr int kHeavyP = EXP_HEAVYP;        // sample reads from which a patch becomes a whole wave's task
 constexpr int kPatchMax = 512;
@@ -1092,10 +1092,10 @@ constexpr int kPatchMax = 512;
 #define EXP_TASK_SORT 1
 #endif
 #ifndef EXP_INFLIGHT
-#define EXP_INFLIGHT 3
+#define EXP_INFLIGHT 4
 #endif
 #ifndef EXP_INFLIGHT_W
-#define EXP_INFLIGHT_W 2
+#define EXP_INFLIGHT_W 1
 #endif
 constexpr int kWorkBuckets = 16;
 constexpr int kInFlight = EXP_INFLIGHT;    // items a lane group of a LIGHT patch keeps in flight per trip
@@ -1116,6 +1116,11 @@ __device__ __forceinline__ void patch_bin_sum(const PItem* __restrict__ lst, int
   // Issue-bound loop (section 4.2c): no per-item index clamp and no per-item weight select.  A trip reads its NF items at constant
   // offsets from one address -- past the end of a list lie the next lists' items (finite weights, valid rows) and behind the last list
   // kItemTail zeroed items -- and an item past the end takes the ZERO ROW (zq) instead of its query's row: finite x 0 adds nothing.
+  // (no unrolling across trips: hipcc's own 2 x unroll of this loop -- nine instances per patch kind -- cost 28-36 bytes of scratch, a
+  // remainder loop per instance and 11-14 us of the launch: tools/ab_gv_variants.sh, 161 -> 147 us on cold operands)
+#if !defined(EXP_UNROLL) || !EXP_UNROLL
+#pragma unroll 1
+#endif
   for (int i = first; i < n; i += NF * step) {
     const PItem* p = lst + i;
     PItem it[NF];
