@@ -57,10 +57,28 @@ def inputs(Lq, mode):
     return [t.to(dev) for t in (value, shapes, ls, loc, attn)]
 
 
+_COLD = None
+
+
 def timeit(fn, iters=20):
+    """MSDA_COLD=1: a median of per-call timings with 1 GiB written before every call, so that no operand is left in the L2s or the
+    256-MB memory-side cache -- what a once-per-step launch sees (for the grad_value scatter that was the difference
+    between 173 and 198 us).  Default: calls back to back."""
+    global _COLD
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
+    if os.environ.get("MSDA_COLD") == "1":
+        if _COLD is None:
+            _COLD = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for a, b in ev:
+            _COLD.fill_(1.0)
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        return sorted(a.elapsed_time(b) * 1e3 for a, b in ev)[iters // 2]
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):

@@ -10,3 +10,10 @@ run() { tag=$1; shift; env "$@" timeout -k 10 240 python bench.py --no-cpu-basel
         python3 -c "import json,sys; d=json.loads(open('$O/$tag.json').read().strip().splitlines()[-1]); print('$tag', round(d['ms_per_step'],2), 'ms', d.get('gemm_plans'))"; }
 EXTRA=--eager run eager_planned OCPG_PLANNED_GEMM=1 && EXTRA=--eager run eager_atmm OCPG_PLANNED_GEMM=0 && \
 EXTRA= run graph_tune_off OCPG_GEMM_TUNE=0 && EXTRA= run graph_tune_on OCPG_GEMM_TUNE=1 && EXTRA= run graph_tune_fp32 OCPG_GEMM_TUNE_FP32=1 && EXTRA= run graph_no_manual_splitk OCPG_SPLIT_K=0
+# Round 4, second half -- what to measure first next round (section 9 of DESIGN.md, method notes):
+#   4. the MSDeformAttn forward and row-gather kernels on COLD operands (in the step they take 133 / 187 us against 116-122 / 180 back to back):
+#        MSDA_COLD=1 MSDA_MODES=ring MSDA_COLS=1 python tools/bench_msda.py        vs        MSDA_MODES=ring MSDA_COLS=1 python tools/bench_msda.py
+#   5. kernels that hold scratch or sit at a register cliff (compile with -S and read .amdhsa_private_segment_fixed_size / next_free_vgpr):
+#      conv3x3_mfma 164-172 registers + 32 B (three waves per SIMD; 128 would be four), k_conv_n16 168 + 60 B, dal_bwd<*, 8> 241-255 + 144 B
+#      (config #5's wide LayerNorms) -- try `#pragma unroll 1` on their instantiated inner loops first (the scatter's sum loop: 80 -> 74, no scratch, -9 %)
+(MSDA_COLD=1 MSDA_MODES=ring MSDA_COLS=1 timeout -k 10 120 python tools/bench_msda.py 2>&1 | grep "Lq=" | sed "s/^/cold /"; MSDA_MODES=ring MSDA_COLS=1 timeout -k 10 120 python tools/bench_msda.py 2>&1 | grep "Lq=" | sed "s/^/warm /") > $O/msda_cold_vs_warm.txt; cat $O/msda_cold_vs_warm.txt
