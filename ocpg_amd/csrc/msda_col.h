@@ -48,7 +48,7 @@ enum { kSelFar = 0, kSelTotal = 1, kSelUnusedA = 2, kSelCur = 3, kSelNext = 4, k
 // NEXT call (two thresholds: hysteresis), makes it current and clears the word: no kernel of a call sees the state change under it.
 // (Round 4, first half: two adds, a fence, a ticket, a fence and two read-backs per reporting workgroup at the END of the kernel -- on
 // cold operands the reporting workgroups waited for their returning atomics behind the flush traffic and the launch ended 27 us later:
-// 184-188 vs 158 us, tools/ab_gv_sel.sh.  A returning atomic issued early and consumed late kept two registers alive through the sums
+// 184-188 vs 158 us, tools/ab_gv_variants.sh GV_SELECT=1.  A returning atomic issued early and consumed late kept two registers alive through the sums
 // of a kernel at its 80-register cap: 172 vs 160 us.)
 __device__ __forceinline__ void sel_report(int* sel, int far, int total) {
   atomicAdd(reinterpret_cast<unsigned long long*>(sel + kSelFar), ((unsigned long long)(unsigned)far << 32) | (unsigned long long)(unsigned)total);
