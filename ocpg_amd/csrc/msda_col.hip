@@ -1116,6 +1116,9 @@ __device__ __forceinline__ void patch_bin_sum(const PItem* __restrict__ lst, int
   // Issue-bound loop (section 4.2c): no per-item index clamp and no per-item weight select.  A trip reads its NF items at constant
   // offsets from one address -- past the end of a list lie the next lists' items (finite weights, valid rows) and behind the last list
   // kItemTail zeroed items -- and an item past the end takes the ZERO ROW (zq) instead of its query's row: finite x 0 adds nothing.
+  // (Item weights are attention weight x bilinear weight: finite whenever the attention weights are.  A non-finite attention weight
+  // makes its own pixels non-finite in any implementation; here it can also reach the pixels of the list read past -- a step whose
+  // attention weights overflowed has no usable gradient either way.  grad_out rows are never read past a list: that is the zero row.)
   // (no unrolling across trips: hipcc's own 2 x unroll of this loop -- nine instances per patch kind -- cost 28-36 bytes of scratch, a
   // remainder loop per instance and 11-14 us of the launch: tools/ab_gv_variants.sh, 161 -> 147 us on cold operands)
 #if !defined(EXP_UNROLL) || !EXP_UNROLL
