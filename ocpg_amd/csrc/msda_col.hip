@@ -1111,7 +1111,7 @@ constexpr int kInFlight = EXP_INFLIGHT;    // items a lane group of a LIGHT patc
 constexpr int kItemTail = 32;              // zeroed items behind the last list: a trip may read up to 3 * 8 + 7 items past its list's end
 template <int BY, int BX, int step, int NF = 4>
 __device__ __forceinline__ void patch_bin_sum(const PItem* __restrict__ lst, int n, int first, const float* __restrict__ gsj, int zq,
-                                              float4 (&acc)[4]) {
+                                              const PItem* __restrict__ zit, float4 (&acc)[4]) {
 #if EXP_LEAN_SUM
   // Issue-bound loop (section 4.2c): no per-item index clamp and no per-item weight select.  A trip reads its NF items at constant
   // offsets from one address -- past the end of a list lie the next lists' items (finite weights, valid rows) and behind the last list
@@ -1119,7 +1119,7 @@ __device__ __forceinline__ void patch_bin_sum(const PItem* __restrict__ lst, int
   // (Item weights are attention weight x bilinear weight: finite whenever the attention weights are.  A non-finite attention weight
   // makes its own pixels non-finite in any implementation; here it can also reach the pixels of the list read past -- a step whose
   // attention weights overflowed has no usable gradient either way.  grad_out rows are never read past a list: that is the zero row.)
-  // (no unrolling across trips: hipcc's own 2 x unroll of this loop -- nine instances per patch kind -- cost 28-36 bytes of scratch, a
+  // (no unrolling across trips: hipcc's own 2 x unroll of this loop -- nine instances per patch kind -- cost 28-36 bytes of scratch at the 80-register cap, a
   // remainder loop per instance and 11-14 us of the launch: tools/ab_gv_variants.sh, 161 -> 147 us on cold operands)
 #if !defined(EXP_UNROLL) || !EXP_UNROLL
 #pragma unroll 1
@@ -1127,11 +1127,20 @@ __device__ __forceinline__ void patch_bin_sum(const PItem* __restrict__ lst, int
   for (int i = first; i < n; i += NF * step) {
     const PItem* p = lst + i;
     PItem it[NF];
+    float4 g[NF];
+#if defined(EXP_ZERO_ITEM) && EXP_ZERO_ITEM
+    // variant (unmeasured: DESIGN section 9): an item past the end is replaced by a ZEROED item whose row is the zero row, so nothing
+    // of a neighbouring list is ever multiplied -- exact for non-finite attention weights too; + 1 instruction per item
+#pragma unroll
+    for (int u = 0; u < NF; ++u) it[u] = *(i + u * step < n ? p + u * step : zit);
+#pragma unroll
+    for (int u = 0; u < NF; ++u) g[u] = ld4(gsj + it[u].q);
+#else
 #pragma unroll
     for (int u = 0; u < NF; ++u) it[u] = p[u * step];
-    float4 g[NF];
 #pragma unroll
     for (int u = 0; u < NF; ++u) g[u] = ld4(gsj + (i + u * step < n ? it[u].q : zq));
+#endif
 #pragma unroll
     for (int u = 0; u < NF; ++u) {
       const float wy[2] = {it[u].wy0, it[u].wy1};
@@ -1421,7 +1430,7 @@ __global__ __launch_bounds__(NT, 6) void k_scatter_col4(const float* __restrict_
   }
   if (tid >= NT - kItemTail) {        // zeroed items behind the last list (patch_bin_sum reads past the end of a list)
     PItem z;
-    z.wy0 = 0.f; z.wy1 = 0.f; z.lx = 0.f; z.q = 0;
+    z.wy0 = 0.f; z.wy1 = 0.f; z.lx = 0.f; z.q = geo.tmax * D;       // (its row: the zero row)
     items[start[kBins3] + tid - (NT - kItemTail)] = z;
   }
 #if EXP_TASK_SORT
@@ -1449,11 +1458,12 @@ __global__ __launch_bounds__(NT, 6) void k_scatter_col4(const float* __restrict_
   const int odd = grp8 & 1;
   const float* gsj = gs + 4 * j;
   const int zq = geo.tmax * D;
+  const PItem* zit = items + start[kBins3];       // the first of the zeroed items behind the last list
 #define OCPG_PATCH_BIN(BY, BX)                                                                                     \
   {                                                                                                                \
     const bool ok_ = live_ && 2 * pr + BY <= wh && 2 * pc + BX <= ww;                                              \
     const int bk_ = ok_ ? b0 + BY * (ww + 1) + BX : b0;                                                            \
-    patch_bin_sum<BY, BX, STEP_, NF_>(items + start[bk_], ok_ ? cnt[bk_] : 0, first, gsj, zq, acc);               \
+    patch_bin_sum<BY, BX, STEP_, NF_>(items + start[bk_], ok_ ? cnt[bk_] : 0, first, gsj, zq, zit, acc);          \
   }
 #define OCPG_PATCH_ALL                                                                                             \
   OCPG_PATCH_BIN(0, 0) OCPG_PATCH_BIN(0, 1) OCPG_PATCH_BIN(0, 2) OCPG_PATCH_BIN(1, 0) OCPG_PATCH_BIN(1, 1) OCPG_PATCH_BIN(1, 2)  \

@@ -15,5 +15,7 @@ EXTRA= run graph_tune_off OCPG_GEMM_TUNE=0 && EXTRA= run graph_tune_on OCPG_GEMM
 #        MSDA_COLD=1 MSDA_MODES=ring MSDA_COLS=1 python tools/bench_msda.py        vs        MSDA_MODES=ring MSDA_COLS=1 python tools/bench_msda.py
 #   5. kernels that hold scratch or sit at a register cliff (compile with -S and read .amdhsa_private_segment_fixed_size / next_free_vgpr):
 #      conv3x3_mfma 164-172 registers + 32 B (three waves per SIMD; 128 would be four), k_conv_n16 168 + 60 B, dal_bwd<*, 8> 241-255 + 144 B
-#      (config #5's wide LayerNorms) -- try `#pragma unroll 1` on their instantiated inner loops first (the scatter's sum loop: 80 -> 74, no scratch, -9 %)
+#      (config #5's wide LayerNorms) -- try `#pragma unroll 1` on their instantiated inner loops first (the scatter's sum loop: no scratch, -9 %)
 (MSDA_COLD=1 MSDA_MODES=ring MSDA_COLS=1 timeout -k 10 120 python tools/bench_msda.py 2>&1 | grep "Lq=" | sed "s/^/cold /"; MSDA_MODES=ring MSDA_COLS=1 timeout -k 10 120 python tools/bench_msda.py 2>&1 | grep "Lq=" | sed "s/^/warm /") > $O/msda_cold_vs_warm.txt; cat $O/msda_cold_vs_warm.txt
+#   6. the exact-for-non-finite-weights form of the scatter's sum loop: tools/build_variant_one.sh zi ocpg_amd/csrc/msda_col.hip -DEXP_ZERO_ITEM=1 &&
+#      tools/ab_gv_variants.sh "default zi" && OCPG_HIP_LIB=$PWD/ocpg_amd/lib/libocpg_hip_zi.so python -m pytest tests/test_msda_gpu.py -q -m gpu
